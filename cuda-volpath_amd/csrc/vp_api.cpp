@@ -1,0 +1,591 @@
+// vp_api.cpp -- the C ABI of libvolpath_hip.so (include/volpath.h): scene state in HBM and the
+// launches.  Part 1 mirrors the reference's kernel-TU entry points (kernel.cu:354-451, :526-553,
+// :1072-1283, :2320-2370); Part 2 is the additive interface.
+//
+// HBM layout (DESIGN.md "Data layout"): the density volume is stored as one 8-byte (uchar) or
+// 32-byte (float) cell per voxel holding that voxel's clamped 2x2x2 texel neighbourhood, so a
+// trilinear fetch is ONE aligned load; bounds are (max,min) pairs per brick; opacity is a plain
+// float N^3 array; the environment is float4 rows.  No textures, no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/volpath.h"
+#include "vp_bounds.h"
+#include "vp_kernels.h"
+
+namespace
+{
+using namespace vp;
+
+struct State
+{
+    int         device      = 0;
+    bool        dev_ready   = false;
+    int         num_cu      = 0;
+    hipStream_t own_stream  = nullptr;
+    hipStream_t stream      = nullptr;
+    SceneDev    S           = {};
+    bool        quant       = true;
+    bool        have_volume = false, have_env = false, have_sun = false, have_cam = false;
+    void*       d_cells     = nullptr;
+    void*       d_bounds    = nullptr;
+    float*      d_opacity   = nullptr;
+    float4*     d_env       = nullptr;
+    int         env_w = 0, env_h = 0;
+    bool        linear      = false;  // kernel.cu:351: point filtering until set_texture_filter_mode(true)
+    int         brick_next  = 1;
+    int         brick       = 1;
+    int         radius      = 0;
+    int         est         = VP_EST_DECOMP;
+    int         rng         = VP_RNG_SAMPLERH;
+    unsigned    key0 = 0, key1 = 0;
+    unsigned    rank = 0, world = 1;
+    float4*     d_stage       = nullptr;
+    size_t      stage_bytes   = 0;
+    unsigned*   d_queue       = nullptr;
+    unsigned long long* d_counters = nullptr;
+    bool        count       = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<hipEvent_t> event_pool;
+    float       inv_model[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    std::string err;
+};
+State G;
+
+constexpr size_t kMaxStageBytes = (size_t)1 << 30;  // 1 GiB of per-sample staging per launch
+
+int fail(int code, const char* fmt, ...)
+{
+    char    buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    G.err = buf;
+    return code;
+}
+[[noreturn]] void die(const char* what)
+{
+    // the reference's failure mode: checkCudaErrors -> fprintf + exit(EXIT_FAILURE) (helper_cuda.h:566-579)
+    fprintf(stderr, "volpath_hip: %s: %s\n", what, G.err.c_str());
+    exit(EXIT_FAILURE);
+}
+#define HIPCHK(expr)                                                                            \
+    do                                                                                          \
+    {                                                                                           \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(VP_E_NODEVICE, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure_device()
+{
+    if (G.dev_ready) return VP_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(VP_E_NODEVICE, "no HIP device visible");
+    if (G.device >= n) return fail(VP_E_NODEVICE, "device %d out of range (%d visible)", G.device, n);
+    HIPCHK(hipSetDevice(G.device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, G.device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(VP_E_NODEVICE, "device %d is %s; this library carries gfx950 code only", G.device, prop.gcnArchName);
+    G.num_cu = prop.multiProcessorCount;
+    HIPCHK(hipStreamCreateWithFlags(&G.own_stream, hipStreamNonBlocking));
+    if (!G.stream) G.stream = G.own_stream;
+    HIPCHK(hipMalloc((void**)&G.d_queue, 256));
+    HIPCHK(hipMalloc((void**)&G.d_counters, 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(G.d_counters, 0, 8 * sizeof(unsigned long long)));
+    G.S.sun_cos = 94.0f / sqrtf(94.0f * 94.0f + 0.45f * 0.45f);                    // kernel.cu:1263
+    G.S.cam_z   = (float)(-1.0f / tan((double)54.43f * 0.00872664626));             // kernel.cu:1981-1985
+    G.dev_ready = true;
+    return VP_OK;
+}
+
+int free_volume()
+{
+    if (G.d_cells) HIPCHK(hipFree(G.d_cells));
+    if (G.d_bounds) HIPCHK(hipFree(G.d_bounds));
+    if (G.d_opacity) HIPCHK(hipFree(G.d_opacity));
+    G.d_cells = G.d_bounds = nullptr;
+    G.d_opacity   = nullptr;
+    G.S.cells_u8  = nullptr;
+    G.S.cells_f32 = nullptr;
+    G.S.bounds_u8 = nullptr;
+    G.S.bounds_f32 = nullptr;
+    G.S.opacity    = nullptr;
+    G.have_volume  = false;
+    return VP_OK;
+}
+
+int do_init_volume(const void* h_volume, vp_extent ext, bool quantized, const vp_float3* bmin, const vp_float3* bmax)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (ext.width == 0 || ext.height == 0 || ext.depth == 0) return fail(VP_E_ARG, "empty volume extent");
+    size_t n = ext.width * ext.height * ext.depth;
+    if (n > ((size_t)1 << 32) - 1) return fail(VP_E_ARG, "volume of %zu voxels exceeds the 2^32 cell index", n);
+    HIPCHK(hipStreamSynchronize(G.stream));
+    rc = free_volume();
+    if (rc) return rc;
+    const int nx = (int)ext.width, ny = (int)ext.height, nz = (int)ext.depth;
+    SceneDev& S = G.S;
+    S.nx = nx; S.ny = ny; S.nz = nz;
+    if (bmin && bmax)
+    {
+        S.bmin[0] = bmin->x; S.bmin[1] = bmin->y; S.bmin[2] = bmin->z;
+        S.bmax[0] = bmax->x; S.bmax[1] = bmax->y; S.bmax[2] = bmax->z;
+    }
+    else
+    {
+        // kernel.cu:373-378
+        S.bmin[0] = -1.0f; S.bmin[1] = -(float)ny / (float)nx; S.bmin[2] = -(float)nz / (float)nx;
+        S.bmax[0] = 1.0f;  S.bmax[1] = (float)ny / (float)nx;  S.bmax[2] = (float)nz / (float)nx;
+    }
+    for (int a = 0; a < 3; a++) S.linv[a] = 1.0f / (S.bmax[a] - S.bmin[a]);  // kernel.cu:313
+    G.quant = quantized;
+    // volume -> packed neighbourhood cells
+    const size_t vbytes = n * (quantized ? 1 : 4);
+    void*        d_raw  = nullptr;
+    HIPCHK(hipMalloc(&d_raw, vbytes));
+    HIPCHK(hipMemcpyAsync(d_raw, h_volume, vbytes, hipMemcpyHostToDevice, G.stream));
+    HIPCHK(hipMalloc(&G.d_cells, n * (quantized ? 8 : 32)));
+    if (quantized) launch_pack_u8((const unsigned char*)d_raw, (uint2*)G.d_cells, nx, ny, nz, G.stream);
+    else launch_pack_f32((const float*)d_raw, (float*)G.d_cells, nx, ny, nz, G.stream);
+    HIPCHK(hipGetLastError());
+    // bound table (CPU, overlaps the upload)
+    G.brick  = G.brick_next;
+    G.radius = bound_radius(nx, 0.05f /* search_radius kernel.cu:151 */) + (G.brick > 1 ? 1 : 0);
+    int shift = 0;
+    while ((1 << shift) < G.brick) shift++;
+    S.brick_shift = shift;
+    S.bnx = (nx + G.brick - 1) / G.brick; S.bny = (ny + G.brick - 1) / G.brick; S.bnz = (nz + G.brick - 1) / G.brick;
+    const size_t nb = (size_t)S.bnx * S.bny * S.bnz;
+    if (quantized)
+    {
+        std::vector<uint8_t> b(nb * 2);
+        build_bounds_u8((const uint8_t*)h_volume, nx, ny, nz, G.radius, G.brick, b.data());
+        HIPCHK(hipMalloc(&G.d_bounds, nb * 2));
+        HIPCHK(hipMemcpy(G.d_bounds, b.data(), nb * 2, hipMemcpyHostToDevice));
+        S.bounds_u8 = (const unsigned char*)G.d_bounds;
+        S.cells_u8  = (const uint2*)G.d_cells;
+    }
+    else
+    {
+        std::vector<float> b(nb * 2);
+        build_bounds_f32((const float*)h_volume, nx, ny, nz, G.radius, G.brick, b.data());
+        HIPCHK(hipMalloc(&G.d_bounds, nb * 8));
+        HIPCHK(hipMemcpy(G.d_bounds, b.data(), nb * 8, hipMemcpyHostToDevice));
+        S.bounds_f32 = (const float*)G.d_bounds;
+        S.cells_f32  = (const float*)G.d_cells;
+    }
+    HIPCHK(hipStreamSynchronize(G.stream));  // caller may free h_volume on return (host.cpp:1343)
+    HIPCHK(hipFree(d_raw));
+    S.linear      = G.linear ? 1 : 0;
+    G.have_volume = true;
+    return VP_OK;
+}
+
+int do_opacity(const float* dir)
+{
+    if (!G.have_volume) return fail(VP_E_STATE, "precompute_opacity before init_cuda");
+    size_t n = (size_t)G.S.nx * G.S.ny * G.S.nz;
+    if (!G.d_opacity) HIPCHK(hipMalloc((void**)&G.d_opacity, n * sizeof(float)));
+    SceneDev S = G.S;
+    S.linear   = G.linear ? 1 : 0;
+    launch_opacity(S, G.quant, dir, G.d_opacity, G.stream);
+    HIPCHK(hipGetLastError());
+    G.S.opacity = G.d_opacity;
+    return VP_OK;
+}
+
+int do_envmap(const vp_float4* data, int w, int h)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!data || w <= 0 || h <= 0) return fail(VP_E_ARG, "bad envmap");
+    if (w != G.env_w || h != G.env_h)
+    {
+        HIPCHK(hipStreamSynchronize(G.stream));
+        if (G.d_env) HIPCHK(hipFree(G.d_env));
+        HIPCHK(hipMalloc((void**)&G.d_env, (size_t)w * h * sizeof(float4)));
+        G.env_w = w; G.env_h = h;
+    }
+    HIPCHK(hipMemcpyAsync(G.d_env, data, (size_t)w * h * sizeof(float4), hipMemcpyHostToDevice, G.stream));
+    HIPCHK(hipStreamSynchronize(G.stream));  // caller owns `data`
+    G.S.env = G.d_env; G.S.env_w = w; G.S.env_h = h;
+    G.have_env = true;
+    return VP_OK;
+}
+
+hipEvent_t get_event()
+{
+    if (!G.event_pool.empty()) { hipEvent_t e = G.event_pool.back(); G.event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int do_render(vp_float4* d_out, int first, int nframes, const Param* p)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!G.have_volume) return fail(VP_E_STATE, "render before init_cuda");
+    if (!G.have_env) return fail(VP_E_STATE, "render before init_envmap");
+    if (!G.have_sun) return fail(VP_E_STATE, "render before set_sun");
+    if (!G.have_cam) return fail(VP_E_STATE, "render before copy_inv_view_matrix");
+    if (!d_out || !p || nframes <= 0 || first < 0) return fail(VP_E_ARG, "bad render arguments");
+    if (p->width == 0 || p->height == 0 || p->width > 65535 || p->height > 65535)
+        return fail(VP_E_ARG, "image %ux%u out of range (sampler.h packs x<<16|y)", p->width, p->height);
+    if (G.est == VP_EST_DECOMP && first + nframes - 1 > 10 && !G.S.opacity)
+        return fail(VP_E_NOOPACITY, "frames beyond 10 need precompute_opacity (kernel.cu:2183, host.cpp:336-343)");
+    LaunchDev L = {};
+    static_assert(sizeof(ParamDev) == sizeof(Param) && sizeof(Param) == 44, "Param layout (param.h:4-12)");
+    memcpy(&L.P, p, sizeof(Param));
+    L.tiles_x = (p->width + 7) / 8;
+    L.tiles_y = (p->height + 7) / 8;
+    unsigned ntiles = L.tiles_x * L.tiles_y;
+    L.rank = G.rank; L.world = G.world;
+    L.ntiles_owned = ntiles > G.rank ? (ntiles - G.rank + G.world - 1) / G.world : 0;
+    L.out = (float4*)d_out;
+    L.queue = G.d_queue;
+    L.counters = G.count ? G.d_counters : nullptr;
+    L.key0 = G.key0; L.key1 = G.key1;
+    if (L.ntiles_owned == 0) return VP_OK;
+    const size_t per_frame = (size_t)L.ntiles_owned * 64;
+    size_t max_f = kMaxStageBytes / (per_frame * sizeof(float4));
+    if (max_f < 1) max_f = 1;
+    size_t cap_items = 0xfffffff0u / per_frame;
+    if (cap_items < 1) return fail(VP_E_ARG, "image too large for the 32-bit sample queue");
+    if (max_f > cap_items) max_f = cap_items;
+    SceneDev S = G.S;
+    S.linear   = G.linear ? 1 : 0;
+    for (int done = 0; done < nframes;)
+    {
+        int f = (int)std::min<size_t>((size_t)(nframes - done), max_f);
+        L.frame0 = first + done;
+        L.nframes = f;
+        L.total_items = (unsigned)(per_frame * (size_t)f);
+        if (f > 1)
+        {
+            size_t need = per_frame * (size_t)f * sizeof(float4);
+            if (need > G.stage_bytes)
+            {
+                HIPCHK(hipStreamSynchronize(G.stream));
+                if (G.d_stage) HIPCHK(hipFree(G.d_stage));
+                HIPCHK(hipMalloc((void**)&G.d_stage, need));
+                G.stage_bytes = need;
+            }
+            L.stage = G.d_stage;
+        }
+        else
+            L.stage = nullptr;
+        HIPCHK(hipMemsetAsync(G.d_queue, 0, sizeof(unsigned), G.stream));
+        unsigned waves  = (L.total_items + 63) / 64;
+        unsigned blocks = (waves + (VP_BLOCK / 64) - 1) / (VP_BLOCK / 64);
+        unsigned cap    = (unsigned)G.num_cu * 8u;
+        if (blocks > cap) blocks = cap;
+        hipEvent_t e0 = get_event(), e1 = get_event();
+        HIPCHK(hipEventRecord(e0, G.stream));
+        launch_render(S, L, G.est, G.rng, G.quant, G.count, (int)blocks, G.stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e1, G.stream));
+        G.events.emplace_back(e0, e1);
+        if (L.stage)
+        {
+            launch_reduce(L, G.stream);
+            HIPCHK(hipGetLastError());
+        }
+        done += f;
+    }
+    return VP_OK;
+}
+}  // namespace
+
+// =============================================================================== Part 1
+extern "C" {
+
+void init_cuda(void* h_volume, vp_extent volumeSize, bool quantized, const vp_float3* boxmin, const vp_float3* boxmax)
+{
+    if (!h_volume)
+    {
+        fprintf(stderr, "cannot init without host volume\n");  // kernel.cu:360-364
+        exit(1);
+    }
+    if (do_init_volume(h_volume, volumeSize, quantized, boxmin, boxmax)) die("init_cuda");
+}
+
+void set_texture_filter_mode(bool bLinearFilter) { G.linear = bLinearFilter; G.S.linear = bLinearFilter ? 1 : 0; }
+
+void free_cuda_buffers(void)
+{
+    if (!G.dev_ready) return;
+    (void)hipStreamSynchronize(G.stream);
+    if (free_volume()) die("free_cuda_buffers");
+}
+
+void precompute_opacity(const float* light_dir)
+{
+    if (do_opacity(light_dir)) die("precompute_opacity");
+}
+
+void init_envmap(const vp_float4* HDRmap, int width, int height)
+{
+    if (do_envmap(HDRmap, width, height)) die("init_envmap");
+}
+
+void free_envmap(void)
+{
+    if (!G.have_env) return;
+    (void)hipStreamSynchronize(G.stream);
+    (void)hipFree(G.d_env);
+    G.d_env = nullptr; G.S.env = nullptr; G.env_w = G.env_h = 0; G.have_env = false;
+}
+
+void set_sun(float* sun_dir, float* sun_power)
+{
+    // kernel.cu:1269-1283: disc radiance kept for the depth-0 sun test, directional power = p * pi * (0.45/94)^2
+    float r = (float)(0.45 / (double)94.0f);
+    float f = 3.1415926535897932384626422832795028841971f * (r * r);
+    for (int i = 0; i < 3; i++)
+    {
+        G.S.sun_dir[i]   = sun_dir[i];
+        G.S.sun_orig[i]  = sun_power[i];
+        G.S.sun_power[i] = sun_power[i] * f;
+    }
+    G.have_sun = true;
+}
+
+void copy_inv_view_matrix(float* invViewMatrix, size_t sizeofMatrix)
+{
+    memcpy(G.S.cam, invViewMatrix, sizeofMatrix < sizeof G.S.cam ? sizeofMatrix : sizeof G.S.cam);
+    G.have_cam = true;
+}
+void copy_inv_model_matrix(float* invModelMatrix, size_t sizeofMatrix)
+{
+    // kept for interface parity; unused while USE_MODEL_TRANSFORM=0 (kernel.cu:32)
+    memcpy(G.inv_model, invModelMatrix, sizeofMatrix < sizeof G.inv_model ? sizeofMatrix : sizeof G.inv_model);
+}
+
+void init_rng(vp_dim3, vp_dim3, int, int) {}  // kernel.cu:2330
+void free_rng(void) {}                         // kernel.cu:2331
+
+void render_kernel(vp_dim3, vp_dim3, vp_float4* d_output, int spp, const Param& p)
+{
+    if (do_render(d_output, spp, 1, &p)) die("render_kernel");
+}
+
+void scale(vp_float4* dst, vp_float4* src, int size, float s)
+{
+    if (ensure_device()) die("scale");
+    launch_scale((float4*)dst, (const float4*)src, size, s, G.stream);
+}
+void gamma_correct(vp_float4* dst, vp_float4* src, int size, float s, float gamma)
+{
+    if (ensure_device()) die("gamma_correct");
+    launch_gamma((float4*)dst, (const float4*)src, size, s, 1.0f / gamma, G.stream);  // kernel.cu:2361
+}
+
+// =============================================================================== Part 2
+const char* vp_last_error(void) { return G.err.c_str(); }
+const char* vp_version(void) { return "volpath_hip 0.1 (gfx950)"; }
+int vp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int vp_set_device(int device)
+{
+    if (G.dev_ready && device != G.device) return fail(VP_E_STATE, "device already initialised as %d", G.device);
+    G.device = device;
+    return ensure_device();
+}
+int vp_set_stream(void* s)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(G.stream));
+    G.stream = s ? (hipStream_t)s : G.own_stream;
+    return VP_OK;
+}
+int vp_synchronize(void)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(G.stream));
+    return VP_OK;
+}
+int vp_set_estimator(int est)
+{
+    if (est != VP_EST_GLOBAL && est != VP_EST_DECOMP) return fail(VP_E_ARG, "unknown estimator %d", est);
+    G.est = est;
+    return VP_OK;
+}
+int vp_set_rng(int mode, uint32_t k0, uint32_t k1)
+{
+    if (mode != VP_RNG_SAMPLERH && mode != VP_RNG_PHILOX) return fail(VP_E_ARG, "unknown rng %d", mode);
+    G.rng = mode; G.key0 = k0; G.key1 = k1;
+    return VP_OK;
+}
+int vp_set_bound_brick(int brick)
+{
+    if (brick < 1 || brick > 64 || (brick & (brick - 1))) return fail(VP_E_ARG, "brick edge must be a power of two in [1,64]");
+    G.brick_next = brick;
+    return VP_OK;
+}
+int vp_set_shard(int rank, int world)
+{
+    if (world < 1 || rank < 0 || rank >= world) return fail(VP_E_ARG, "bad shard %d/%d", rank, world);
+    G.rank = (unsigned)rank; G.world = (unsigned)world;
+    return VP_OK;
+}
+int vp_render_frames(vp_float4* d_output, int first_frame, int n_frames, const Param* p)
+{
+    return do_render(d_output, first_frame, n_frames, p);
+}
+int vp_enable_counters(int on) { G.count = on != 0; return VP_OK; }
+int vp_read_counters(vp_counters* out, int reset)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(G.stream));
+    unsigned long long h[8];
+    HIPCHK(hipMemcpy(h, G.d_counters, sizeof h, hipMemcpyDeviceToHost));
+    if (out)
+    {
+        memset(out, 0, sizeof *out);
+        out->samples = h[0]; out->density_lookups = h[1]; out->density_loads = h[1]; out->bound_lookups = h[2];
+        out->opacity_lookups = h[3]; out->env_lookups = h[4]; out->scatters = h[5];
+    }
+    if (reset) HIPCHK(hipMemset(G.d_counters, 0, sizeof h));
+    return VP_OK;
+}
+int vp_render_time_ms(double* total_ms, int* launches, int reset)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(G.stream));
+    double tot = 0;
+    for (auto& ev : G.events)
+    {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int)G.events.size();
+    if (reset)
+    {
+        for (auto& ev : G.events) { G.event_pool.push_back(ev.first); G.event_pool.push_back(ev.second); }
+        G.events.clear();
+    }
+    return VP_OK;
+}
+int vp_get_bound_table(void* dst, size_t bytes, int* bnx, int* bny, int* bnz, int* brick, int* radius)
+{
+    if (!G.have_volume) return fail(VP_E_STATE, "no volume");
+    size_t need = (size_t)G.S.bnx * G.S.bny * G.S.bnz * (G.quant ? 2 : 8);
+    if (bnx) *bnx = G.S.bnx;
+    if (bny) *bny = G.S.bny;
+    if (bnz) *bnz = G.S.bnz;
+    if (brick) *brick = G.brick;
+    if (radius) *radius = G.radius;
+    if (dst)
+    {
+        if (bytes < need) return fail(VP_E_ARG, "bound table needs %zu bytes", need);
+        HIPCHK(hipMemcpy(dst, G.d_bounds, need, hipMemcpyDeviceToHost));
+    }
+    return VP_OK;
+}
+int vp_get_opacity(float* dst, size_t count)
+{
+    if (!G.d_opacity) return fail(VP_E_STATE, "no opacity table");
+    size_t n = (size_t)G.S.nx * G.S.ny * G.S.nz;
+    if (count < n) return fail(VP_E_ARG, "opacity needs %zu floats", n);
+    HIPCHK(hipStreamSynchronize(G.stream));
+    HIPCHK(hipMemcpy(dst, G.d_opacity, n * sizeof(float), hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+
+int vp_test_math(int which, const float* in, float* out, int n)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    float *di = nullptr, *d_o = nullptr;
+    HIPCHK(hipMalloc((void**)&di, (size_t)n * 4));
+    HIPCHK(hipMalloc((void**)&d_o, (size_t)n * 4));
+    HIPCHK(hipMemcpy(di, in, (size_t)n * 4, hipMemcpyHostToDevice));
+    launch_test_math(which, di, d_o, n, G.stream);
+    HIPCHK(hipStreamSynchronize(G.stream));
+    HIPCHK(hipMemcpy(out, d_o, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(di));
+    HIPCHK(hipFree(d_o));
+    return VP_OK;
+}
+int vp_test_rng(int mode, uint32_t x, uint32_t y, uint32_t frame, uint32_t k0, uint32_t k1, int n, float* out)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    float* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)n * 4));
+    launch_test_rng(mode, x, y, frame, k0, k1, n, d, G.stream);
+    HIPCHK(hipStreamSynchronize(G.stream));
+    HIPCHK(hipMemcpy(out, d, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(d));
+    return VP_OK;
+}
+int vp_test_sample_density(const float* pos_xyz, float* out, int n)
+{
+    if (!G.have_volume) return fail(VP_E_STATE, "no volume");
+    float *dp = nullptr, *dq = nullptr;
+    HIPCHK(hipMalloc((void**)&dp, (size_t)n * 12));
+    HIPCHK(hipMalloc((void**)&dq, (size_t)n * 4));
+    HIPCHK(hipMemcpy(dp, pos_xyz, (size_t)n * 12, hipMemcpyHostToDevice));
+    SceneDev S = G.S;
+    S.linear   = G.linear ? 1 : 0;
+    launch_test_density(S, G.quant, dp, dq, n, G.stream);
+    HIPCHK(hipStreamSynchronize(G.stream));
+    HIPCHK(hipMemcpy(out, dq, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(dp));
+    HIPCHK(hipFree(dq));
+    return VP_OK;
+}
+
+void* vp_malloc(size_t bytes)
+{
+    if (ensure_device()) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { fail(VP_E_NODEVICE, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+int vp_free(void* p) { HIPCHK(hipFree(p)); return VP_OK; }
+int vp_memset(void* p, int v, size_t bytes)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(p, v, bytes, G.stream));
+    return VP_OK;
+}
+int vp_upload(void* d, const void* s, size_t bytes)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, G.stream));
+    HIPCHK(hipStreamSynchronize(G.stream));
+    return VP_OK;
+}
+int vp_download(void* d, const void* s, size_t bytes)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(G.stream));
+    HIPCHK(hipMemcpy(d, s, bytes, hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+}  // extern "C"

@@ -1,0 +1,352 @@
+// vp_device.h -- device-side building blocks of the gfx950 radiance integrator.
+//
+// Arithmetic contract: binary32, no contraction, left-to-right; texture fetches of the reference
+// (tex3D / tex2D, kernel.cu:173-178, :971) are explicit loads + ALU filtering; see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vp_math.h"
+
+namespace vp
+{
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b)
+{
+    return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ f3 normalize(f3 v) { return v * (1.0f / __builtin_sqrtf(dot(v, v))); }
+__device__ __forceinline__ float max3(f3 v) { return fmaxf(fmaxf(v.x, v.y), v.z); }
+__device__ __forceinline__ float min3(f3 v) { return fminf(fminf(v.x, v.y), v.z); }
+
+// vecmath.h:9-16 evaluated in float, as the reference's constexpr does
+#define VP_PI_F 3.1415926535897932384626422832795028841971f
+constexpr float kPi     = VP_PI_F;
+constexpr float kPi2    = VP_PI_F / 2.0f;
+constexpr float k1Pi    = 1.0f / VP_PI_F;
+constexpr float k1TwoPi = 1.0f / (VP_PI_F * 2.0f);
+
+// Param of the reference (src/param.h:4-12); 44 bytes
+struct ParamDev
+{
+    unsigned width, height;
+    float    density, brightness;
+    float    albedo[3];
+    float    g;
+    float    sigma_t[3];
+};
+
+// Everything the integrator reads besides Param; uniform (kernel argument, scalar loads)
+struct SceneDev
+{
+    const uint2*         cells_u8;   // quantized volume: the 2x2x2 texel neighbourhood of each voxel in 8 bytes
+    const float*         cells_f32;  // float volume: the same neighbourhood as 8 floats
+    const unsigned char* bounds_u8;  // (max,min) byte pairs per brick
+    const float*         bounds_f32; // (max,min) float pairs per brick
+    const float*         opacity;    // optical depth toward the sun, N^3 floats (or null)
+    const float4*        env;        // lat-long environment, row 0 = zenith
+    int   nx, ny, nz, linear;
+    int   brick_shift, bnx, bny, bnz;
+    int   env_w, env_h;
+    float bmin[3], bmax[3], linv[3];
+    float sun_dir[3], sun_power[3], sun_orig[3];
+    float sun_cos;   // 94 / sqrt(94^2 + 0.45^2), kernel.cu:1263
+    float cam[12];   // row-major 3x4 camera-to-world, kernel.cu:626
+    float cam_z;     // -1 / tan(54.43 * 0.00872664626), kernel.cu:1985
+};
+
+// ------------------------------------------------------------------------------ RNG
+// sampler.h:3-11
+__device__ __forceinline__ unsigned wang_hash(unsigned seed)
+{
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed *= 9u;
+    seed = seed ^ (seed >> 4);
+    seed *= 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return seed;
+}
+
+// sampler.h-compatible stream (parity mode; quirk Q2)
+struct RngSamplerH
+{
+    unsigned sx, sy;
+    __device__ __forceinline__ void init(unsigned px, unsigned py, unsigned frame, unsigned, unsigned)
+    {
+        sx = wang_hash((px << 16) | py);
+        sy = wang_hash(frame);
+        word();
+    }
+    __device__ __forceinline__ unsigned word()
+    {
+        unsigned result = sx * 0x9e3779bbu;
+        sy ^= sx;
+        sx = ((sx << 26) | (sx >> 6)) ^ sy ^ (sy << 9);
+        sy = (sx << 13) | (sx >> 19);
+        return result;
+    }
+    __device__ __forceinline__ float next() { return u2f(0x3f800000u | (word() >> 9)) - 1.0f; }
+};
+
+// Philox4x32-10 (Salmon et al. 2011), counter = (x, y, frame, draw/4), key = (k0, k1)
+struct RngPhilox
+{
+    unsigned cx, cy, cf, n, k0, k1;
+    unsigned b0, b1, b2, b3;
+    __device__ __forceinline__ void init(unsigned px, unsigned py, unsigned frame, unsigned key0, unsigned key1)
+    {
+        cx = px; cy = py; cf = frame; n = 0; k0 = key0; k1 = key1;
+        b0 = b1 = b2 = b3 = 0;
+    }
+    __device__ __forceinline__ void block(unsigned blk)
+    {
+        unsigned c0 = cx, c1 = cy, c2 = cf, c3 = blk, ka = k0, kb = k1;
+#pragma unroll
+        for (int r = 0; r < 10; r++)
+        {
+            unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+            unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+            unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ ka;
+            unsigned n1 = (unsigned)p1;
+            unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ kb;
+            unsigned n3 = (unsigned)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            ka += 0x9E3779B9u;
+            kb += 0xBB67AE85u;
+        }
+        b0 = c0; b1 = c1; b2 = c2; b3 = c3;
+    }
+    __device__ __forceinline__ unsigned word()
+    {
+        unsigned q = n & 3u;
+        if (q == 0) block(n >> 2);
+        n++;
+        unsigned w = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
+        return w;
+    }
+    __device__ __forceinline__ float next() { return u2f(0x3f800000u | (word() >> 9)) - 1.0f; }
+};
+
+// ------------------------------------------------------------------ texture fetches
+#define VP_U8_TRI_SCALE 2.3374372e-10f  // fl(1/(255*2^24)): full scale -> exactly 1.0f
+#define VP_U8_SCALE 0.003921569f        // fl(1/255)
+
+__device__ __forceinline__ f3 to_local(const SceneDev& S, f3 pos)
+{
+    return f3{(pos.x - S.bmin[0]) * S.linv[0], (pos.y - S.bmin[1]) * S.linv[1], (pos.z - S.bmin[2]) * S.linv[2]};
+}
+
+// texel-centre split of one axis: cell index (clamped) and 8-bit weight in 0..256
+__device__ __forceinline__ void axis_linear(float pn, int n, int& i, int& w)
+{
+    float x  = pn * (float)n;
+    float xb = x - 0.5f;
+    float fl = __builtin_floorf(xb);
+    float fr = xb - fl;
+    i        = (int)fl;
+    w        = (int)__builtin_floorf(fr * 256.0f + 0.5f);
+    // the packed cell of voxel i already holds the clamped (i, i+1) pair; i < 0 degenerates to texel 0
+    w = i < 0 ? 0 : w;
+    i = i < 0 ? 0 : i;
+    i = i > n - 1 ? n - 1 : i;
+}
+__device__ __forceinline__ int axis_point(float pn, int n)
+{
+    int i = (int)__builtin_floorf(pn * (float)n);
+    i     = i < 0 ? 0 : i;
+    i     = i > n - 1 ? n - 1 : i;
+    return i;
+}
+
+__device__ __forceinline__ float lerpf(float a, float b, float w) { return a * (1.0f - w) + b * w; }
+
+// filter the 8 bytes of a packed cell; exact integer arithmetic, one multiply to normalise
+__device__ __forceinline__ float filter_cell_u8(uint2 c, unsigned wx, unsigned wy, unsigned wz)
+{
+    unsigned t000 = c.x & 0xffu, t100 = (c.x >> 8) & 0xffu, t010 = (c.x >> 16) & 0xffu, t110 = c.x >> 24;
+    unsigned t001 = c.y & 0xffu, t101 = (c.y >> 8) & 0xffu, t011 = (c.y >> 16) & 0xffu, t111 = c.y >> 24;
+    unsigned ix   = 256u - wx, iy = 256u - wy, iz = 256u - wz;
+    unsigned x00  = t000 * ix + t100 * wx;
+    unsigned x10  = t010 * ix + t110 * wx;
+    unsigned x01  = t001 * ix + t101 * wx;
+    unsigned x11  = t011 * ix + t111 * wx;
+    unsigned y0   = x00 * iy + x10 * wy;
+    unsigned y1   = x01 * iy + x11 * wy;
+    unsigned v    = y0 * iz + y1 * wz;
+    return (float)v * VP_U8_TRI_SCALE;
+}
+
+// normalised density in [0,1] at a world position: tex3D<float>(density_tex) of kernel.cu:692
+template <bool QUANT>
+__device__ __forceinline__ float sample_density01(const SceneDev& S, f3 pos)
+{
+    f3  p = to_local(S, pos);
+    int i, j, k, wx, wy, wz;
+    if (S.linear)
+    {
+        axis_linear(p.x, S.nx, i, wx);
+        axis_linear(p.y, S.ny, j, wy);
+        axis_linear(p.z, S.nz, k, wz);
+    }
+    else
+    {
+        i = axis_point(p.x, S.nx);
+        j = axis_point(p.y, S.ny);
+        k = axis_point(p.z, S.nz);
+        wx = wy = wz = 0;
+    }
+    size_t idx = (size_t)((unsigned)i + (unsigned)S.nx * ((unsigned)j + (unsigned)S.ny * (unsigned)k));
+    if (QUANT)
+    {
+        uint2 c = S.cells_u8[idx];
+        return filter_cell_u8(c, (unsigned)wx, (unsigned)wy, (unsigned)wz);
+    }
+    else
+    {
+        const float4* q  = reinterpret_cast<const float4*>(S.cells_f32) + idx * 2;
+        float4        lo = q[0], hi = q[1];
+        float fx = (float)wx * (1.0f / 256.0f), fy = (float)wy * (1.0f / 256.0f), fz = (float)wz * (1.0f / 256.0f);
+        float x00 = lerpf(lo.x, lo.y, fx);
+        float x10 = lerpf(lo.z, lo.w, fx);
+        float x01 = lerpf(hi.x, hi.y, fx);
+        float x11 = lerpf(hi.z, hi.w, fx);
+        float y0  = lerpf(x00, x10, fy);
+        float y1  = lerpf(x01, x11, fy);
+        return lerpf(y0, y1, fz);
+    }
+}
+
+// trilinear fetch from a plain float volume (the opacity table, kernel.cu:541-542, :2187)
+__device__ __forceinline__ float sample_float_volume(const SceneDev& S, const float* vol, f3 pos)
+{
+    f3 p = to_local(S, pos);
+    int   n[3]  = {S.nx, S.ny, S.nz};
+    float pn[3] = {p.x, p.y, p.z};
+    int   a[3], b[3];
+    float w[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++)
+    {
+        float x  = pn[ax] * (float)n[ax];
+        float xb = x - 0.5f;
+        float fl = __builtin_floorf(xb);
+        float fr = xb - fl;
+        int   i  = (int)fl;
+        w[ax]    = (float)(int)__builtin_floorf(fr * 256.0f + 0.5f) * (1.0f / 256.0f);
+        int i0 = i < 0 ? 0 : i;     i0 = i0 > n[ax] - 1 ? n[ax] - 1 : i0;
+        int i1 = i + 1 < 0 ? 0 : i + 1; i1 = i1 > n[ax] - 1 ? n[ax] - 1 : i1;
+        a[ax] = i0; b[ax] = i1;
+    }
+    size_t sx = 1, sy = (size_t)S.nx, sz = (size_t)S.nx * S.ny;
+    float x00 = lerpf(vol[a[0] * sx + a[1] * sy + a[2] * sz], vol[b[0] * sx + a[1] * sy + a[2] * sz], w[0]);
+    float x10 = lerpf(vol[a[0] * sx + b[1] * sy + a[2] * sz], vol[b[0] * sx + b[1] * sy + a[2] * sz], w[0]);
+    float x01 = lerpf(vol[a[0] * sx + a[1] * sy + b[2] * sz], vol[b[0] * sx + a[1] * sy + b[2] * sz], w[0]);
+    float x11 = lerpf(vol[a[0] * sx + b[1] * sy + b[2] * sz], vol[b[0] * sx + b[1] * sy + b[2] * sz], w[0]);
+    float y0  = lerpf(x00, x10, w[1]);
+    float y1  = lerpf(x01, x11, w[1]);
+    return lerpf(y0, y1, w[2]);
+}
+
+// point-sampled (max,min) bound of the brick containing pos: vol_bound_minmax kernel.cu:1610-1624
+template <bool QUANT>
+__device__ __forceinline__ void sample_bound(const SceneDev& S, f3 pos, float& bmax, float& bmin)
+{
+    f3  p = to_local(S, pos);
+    int i = axis_point(p.x, S.nx) >> S.brick_shift;
+    int j = axis_point(p.y, S.ny) >> S.brick_shift;
+    int k = axis_point(p.z, S.nz) >> S.brick_shift;
+    size_t o = (size_t)((unsigned)i + (unsigned)S.bnx * ((unsigned)j + (unsigned)S.bny * (unsigned)k));
+    if (QUANT)
+    {
+        unsigned short v = reinterpret_cast<const unsigned short*>(S.bounds_u8)[o];
+        bmax = (float)(v & 0xffu) * VP_U8_SCALE;
+        bmin = (float)(v >> 8) * VP_U8_SCALE;
+    }
+    else
+    {
+        float2 v = reinterpret_cast<const float2*>(S.bounds_f32)[o];
+        bmax = v.x;
+        bmin = v.y;
+    }
+}
+
+// eval_envmap kernel.cu:956-973 with dir_to_uv :882-895; point sampled, clamped
+__device__ __forceinline__ f3 eval_envmap(const SceneDev& S, f3 dir)
+{
+    float phi   = acosf_(dir.y);
+    float theta = atanf_(dir.z / dir.x) + kPi2;
+    if (dir.x < 0.0f) theta += kPi;
+    float  u = theta * k1TwoPi;
+    float  v = phi * k1Pi;
+    int    i = axis_point(u, S.env_w);
+    int    j = axis_point(v, S.env_h);
+    float4 t = S.env[(size_t)i + (size_t)S.env_w * (size_t)j];
+    return f3{t.x, t.y, t.z};
+}
+
+// intersectBox kernel.cu:654-680 (quirk Q13)
+__device__ __forceinline__ bool intersect_box(f3 o, f3 d, const SceneDev& S, float& tnear, float& tfar)
+{
+    f3 invR = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    f3 tbot = invR * (f3{S.bmin[0], S.bmin[1], S.bmin[2]} - o);
+    f3 ttop = invR * (f3{S.bmax[0], S.bmax[1], S.bmax[2]} - o);
+    f3 tmin = f3{fminf(ttop.x, tbot.x), fminf(ttop.y, tbot.y), fminf(ttop.z, tbot.z)};
+    f3 tmax = f3{fmaxf(ttop.x, tbot.x), fmaxf(ttop.y, tbot.y), fmaxf(ttop.z, tbot.z)};
+    float largest_tmin  = max3(tmin);
+    float smallest_tmax = min3(tmax);
+    tnear = largest_tmin;
+    tfar  = smallest_tmax;
+    return smallest_tmax > largest_tmin && smallest_tmax >= 1e-3f;
+}
+
+// Frame kernel.cu:557-573 (fabs(n.x) > 0.1 is a DOUBLE compare: equivalent to >= 0.1f in float)
+struct Frame
+{
+    f3 n, t, b;
+    __device__ __forceinline__ explicit Frame(f3 normal)
+    {
+        n    = normal;
+        f3 a = (__builtin_fabsf(n.x) >= 0.1f) ? f3{0.0f, 1.0f, 0.0f} : f3{1.0f, 0.0f, 0.0f};
+        t    = normalize(cross(a, n));
+        b    = cross(n, t);
+    }
+    __device__ __forceinline__ f3 to_world(f3 c) const { return (t * c.x + b * c.y) + n * c.z; }
+};
+
+// HGPhaseFunction::sample kernel.cu:580-598 (quirk Q1)
+__device__ __forceinline__ f3 hg_sample_local(float g, float rnd0, float rnd1)
+{
+    float cos_theta;
+    if (__builtin_fabsf(g) > 1e-6f)
+    {
+        float s   = 2.0f * rnd0 - 1.0f;
+        float f   = (1.0f - g * g) / (1.0f + g * s);
+        cos_theta = (0.5f / g) * (1.0f + g * g - f * f);
+        cos_theta = fmaxf(0.0f, fminf(1.0f, cos_theta));
+    }
+    else
+        cos_theta = 2.0f * rnd0 - 1.0f;
+    float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+    float phi       = (2.0f * kPi) * rnd1;
+    float sp, cp;
+    sincosf_(phi, sp, cp);
+    return f3{cp * sin_theta, sp * sin_theta, cos_theta};
+}
+// HGPhaseFunction::evaluate kernel.cu:600-603
+__device__ __forceinline__ float hg_eval(float g, float cos_theta)
+{
+    return (1.0f - g * g) / ((4.0f * kPi) * pow15f_(1.0f + g * g - (2.0f * g) * cos_theta));
+}
+
+// hyperion trick kernel.cu:2039 / :1358
+__device__ __forceinline__ float hyperion_s(int n_minus)
+{
+    return fmaxf(0.0f, fminf(1.0f, (float)n_minus * 0.066666666666666666667f));
+}
+}  // namespace vp

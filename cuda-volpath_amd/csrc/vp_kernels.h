@@ -1,0 +1,40 @@
+// vp_kernels.h -- launch descriptors and host-callable launchers of vp_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vp_device.h"
+
+#define VP_BLOCK 256
+
+namespace vp
+{
+// same values as the VP_EST_* / VP_RNG_* enums of include/volpath.h
+constexpr int EST_GLOBAL = 0, EST_DECOMP = 1;
+constexpr int RNG_SAMPLERH = 0, RNG_PHILOX = 1;
+
+// one render launch: frames [frame0, frame0+nframes) x the 8x8 pixel tiles this rank owns
+struct LaunchDev
+{
+    ParamDev P;
+    int      frame0, nframes;
+    unsigned tiles_x, tiles_y;
+    unsigned ntiles_owned, rank, world;
+    unsigned total_items;  // nframes * ntiles_owned * 64
+    float4*  out;          // W*H accumulator (caller-owned)
+    float4*  stage;        // [nframes][ntiles_owned*64] per-sample results, or null = accumulate directly
+    unsigned* queue;       // sample queue head (zeroed before the launch)
+    unsigned long long* counters;  // 6 words (samples, density, bound, opacity, env, scatters) or null
+    unsigned key0, key1;   // Philox key
+};
+
+void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int blocks, hipStream_t st);
+void launch_reduce(const LaunchDev& L, hipStream_t st);
+void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, hipStream_t st);
+void launch_pack_f32(const float* vol, float* cells, int nx, int ny, int nz, hipStream_t st);
+void launch_opacity(const SceneDev& S, bool quant, const float dir[3], float* out, hipStream_t st);
+void launch_scale(float4* dst, const float4* src, int size, float s, hipStream_t st);
+void launch_gamma(float4* dst, const float4* src, int size, float s, float inv_gamma, hipStream_t st);
+void launch_test_math(int which, const float* in, float* out, int n, hipStream_t st);
+void launch_test_rng(int mode, unsigned x, unsigned y, unsigned f, unsigned k0, unsigned k1, int n, float* out, hipStream_t st);
+void launch_test_density(const SceneDev& S, bool quant, const float* pos, float* out, int n, hipStream_t st);
+}  // namespace vp

@@ -1,0 +1,572 @@
+// vp_kernels.hip -- gfx950 kernels of the volumetric radiance integrator.
+//
+// render_k: persistent wave64 workgroups pull (frame, pixel) samples from a global queue with
+// one atomic per wave (ballot + mbcnt compaction), so a lane whose path ended is refilled while
+// its neighbours keep tracking; every path carries its own RNG state and therefore computes the
+// same bits wherever and whenever it runs.  One loop iteration = at most one segment set-up, one
+// free-flight step (primary or shadow ray) and one event.  Restates
+//   __d_render_bounded_decomp  kernel.cu:1958-2318  (EST_DECOMP, the reference's live kernel)
+//   __d_render                 kernel.cu:1285-1591  (EST_GLOBAL, BASELINE config 2)
+// under SPECTRAL_TRACKING=1, SUN_LIGHT=1, PASSIVE_ENVMAP=1, PRECOMPUTE_OPACITY=1 (kernel.cu:15-34).
+#include <hip/hip_runtime.h>
+
+#include "vp_device.h"
+#include "vp_kernels.h"
+
+namespace vp
+{
+enum : int { ST_DONE = 0, ST_SETUP = 1, ST_TRACK = 2, ST_SHADOW = 3 };
+
+__device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+template <int EST, class RNG, bool QUANT, bool COUNT>
+__global__ __launch_bounds__(VP_BLOCK) void render_k(SceneDev S, LaunchDev L)
+{
+    const ParamDev& P = L.P;
+    const f3    sun_dir   = f3{S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]};
+    const f3    sun_power = f3{S.sun_power[0], S.sun_power[1], S.sun_power[2]};
+    const f3    sig_t     = f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]};
+    const f3    sig_s     = sig_t * f3{P.albedo[0], P.albedo[1], P.albedo[2]};
+    const float max_sig   = max3(sig_t);
+    const float min_sig   = min3(sig_t);
+    const float density   = P.density;
+
+    // ---- per-lane path state
+    int      st = ST_DONE;
+    bool     exhausted = false;
+    unsigned item = 0;          // queue index of the sample this lane works on
+    unsigned px = 0, py = 0;
+    int      frame = 0;
+    RNG      rng;
+    f3       o = {}, d = {};     // primary ray
+    f3       thr = {}, rad = {};
+    int      nsc = 0;            // num_scatters (DECOMP) / depth i (GLOBAL)
+    // segment (primary tracking)
+    float t_far = 0, dist = 0, distc = 0, inv_sigma = 0, inv_sigma_t = 0, sigma_t_prime = 0, sigma_c = 0;
+    float density_prime = 0, d_max = 0, phase_g = 0;
+    // scatter point + shadow ray
+    f3    pos = {}, sd = {};
+    float s_max_t = 0, s_inv_sigma = 0, s_density = 0, ph = 0;
+    int   terms = 0;
+
+    unsigned long long c_den = 0, c_bnd = 0, c_opa = 0, c_env = 0, c_sca = 0, c_smp = 0;
+
+    const unsigned lane = threadIdx.x & 63u;
+
+    for (;;)
+    {
+        // ------------------------------------------------ refill finished lanes from the queue
+        {
+            bool               need = (st == ST_DONE) && !exhausted;
+            unsigned long long m    = __ballot(need);
+            if (m)
+            {
+                unsigned cnt    = (unsigned)__popcll(m);
+                unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
+                unsigned base   = 0;
+                if (lane == leader) base = atomicAdd(L.queue, cnt);
+                base = (unsigned)__shfl((int)base, (int)leader, 64);
+                if (need)
+                {
+                    item = base + lane_rank(m);
+                    if (item >= L.total_items) exhausted = true;
+                    else
+                    {
+                        unsigned per_frame = L.ntiles_owned * 64u;
+                        unsigned fl  = item / per_frame;
+                        unsigned rem = item - fl * per_frame;
+                        unsigned ot  = rem >> 6, w = rem & 63u;
+                        unsigned t   = ot * L.world + L.rank;
+                        unsigned ty  = t / L.tiles_x, tx = t - ty * L.tiles_x;
+                        px    = tx * 8u + (w & 7u);
+                        py    = ty * 8u + (w >> 3);
+                        frame = L.frame0 + (int)fl;
+                        if (px < P.width && py < P.height)
+                        {
+                            // camera ray, kernel.cu:1977-1987 (quirk Q3)
+                            rng.init(px, py, (unsigned)frame, L.key0, L.key1);
+                            float u = ((float)px * 2.0f - (float)P.width) / (float)P.width;
+                            float v = ((float)py * 2.0f - (float)P.height) / (float)P.width;
+                            o       = f3{S.cam[3], S.cam[7], S.cam[11]};
+                            f3 dv   = f3{u, v, S.cam_z};
+                            d = normalize(f3{dot(dv, f3{S.cam[0], S.cam[1], S.cam[2]}), dot(dv, f3{S.cam[4], S.cam[5], S.cam[6]}),
+                                             dot(dv, f3{S.cam[8], S.cam[9], S.cam[10]})});
+                            thr = f3{1.0f, 1.0f, 1.0f};
+                            rad = f3{0.0f, 0.0f, 0.0f};
+                            nsc = 0;
+                            st  = ST_SETUP;
+                            if (COUNT) c_smp++;
+                        }
+                        // pixels of a partial edge tile outside the image: nothing to do, stay DONE
+                    }
+                }
+            }
+            if (__ballot(st != ST_DONE || !exhausted) == 0ull) break;
+        }
+
+        bool finished = false;  // path ended this iteration: write the sample
+
+        // ------------------------------------------------ segment set-up
+        if (st == ST_SETUP)
+        {
+            float t_near, tf;
+            bool  hit = intersect_box(o, d, S, t_near, tf);
+            if (EST == EST_DECOMP)
+            {
+                // intersectSuperVolume kernel.cu:1626-1661 (quirks Q6, Q10): the bound is fetched before the hit test
+                t_near = fmaxf(t_near, 0.0f);
+                t_far  = fminf(tf, 0.05f);
+                float bx, by;
+                sample_bound<QUANT>(S, o + d * t_near, bx, by);
+                if (COUNT) c_bnd++;
+                float d_min = by;
+                d_max       = fmaxf(0.0001f, bx);
+                if (!hit)
+                {
+                    f3 bg;
+                    if (nsc == 0 && dot(d, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
+                    else { bg = eval_envmap(S, d); if (COUNT) c_env++; }
+                    rad      = rad + bg * thr;
+                    finished = true;
+                }
+                else
+                {
+                    bool use_decomp = d_min > 0.0f;
+                    dist            = t_near;
+                    float s         = hyperion_s(nsc - 5);
+                    phase_g         = (1.0f - s) * P.g;
+                    float reduction = (1.0f - s) + s * (1.0f - P.g);
+                    density_prime   = reduction * density;
+                    sigma_t_prime   = max_sig * density_prime * d_max;
+                    inv_sigma_t     = 1.0f / sigma_t_prime;
+                    if (use_decomp)
+                    {
+                        // analog decomposition tracking kernel.cu:2048-2054 (quirk Q7)
+                        sigma_c       = min_sig * density_prime * d_min;
+                        distc         = dist - logf_(rng.next()) / fmaxf(sigma_c, 1e-20f);
+                        float sigma_r = fmaxf(sigma_t_prime - sigma_c, 1e-20f);
+                        inv_sigma     = 1.0f / sigma_r;
+                    }
+                    else
+                    {
+                        distc     = 1e20f;
+                        sigma_c   = 0.0f;
+                        inv_sigma = inv_sigma_t;
+                    }
+                    st = ST_TRACK;
+                }
+            }
+            else
+            {
+                // __d_render kernel.cu:1332-1370
+                if (!hit)
+                {
+                    f3 bg;
+                    if (nsc == 0 && dot(d, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
+                    else { bg = eval_envmap(S, d); if (COUNT) c_env++; }
+                    rad      = rad + bg * thr;
+                    finished = true;
+                }
+                else
+                {
+                    if (t_near < 0.0f) t_near = 0.0f;
+                    t_far         = tf;
+                    dist          = t_near;
+                    float s       = hyperion_s(nsc - 5);
+                    phase_g       = (1.0f - s) * P.g;
+                    density_prime = (1.0f - s) * density + s * density * (1.0f - P.g);
+                    sigma_t_prime = max_sig * density_prime;
+                    inv_sigma     = 1.0f / sigma_t_prime;
+                    inv_sigma_t   = inv_sigma;
+                    sigma_c       = 0.0f;
+                    distc         = 1e20f;
+                    d_max         = 1.0f;
+                    st            = ST_TRACK;
+                }
+            }
+        }
+
+        // ------------------------------------------------ one free-flight step
+        bool scatter_now = false;  // primary ray reached a (real or control) collision
+        bool nee_done    = false;  // shadow ray finished (or NEE needed no tracking)
+        f3   nee_a       = {1.0f, 1.0f, 1.0f};
+
+        if (st == ST_TRACK)
+        {
+            dist += -logf_(rng.next()) * inv_sigma;
+            bool end = (EST == EST_DECOMP) ? (dist >= distc || dist >= t_far) : (dist >= t_far);
+            if (end)
+            {
+                if (EST == EST_DECOMP)
+                {
+                    pos          = o + d * distc;
+                    bool through = fminf(distc, dist) >= t_far;
+                    if (through)
+                    {
+                        o  = o + d * t_far;  // tracking restart kernel.cu:2151-2155
+                        st = ST_SETUP;
+                    }
+                    else
+                        scatter_now = true;
+                }
+                else
+                {
+                    // transmitted through the whole box: kernel.cu:1444-1452
+                    f3 bg;
+                    if (nsc == 0 && dot(d, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
+                    else { bg = eval_envmap(S, d); if (COUNT) c_env++; }
+                    rad      = rad + bg * thr;
+                    finished = true;
+                }
+            }
+            else
+            {
+                pos       = o + d * dist;
+                float den = sample_density01<QUANT>(S, pos) * density_prime;  // vol_sigma_t kernel.cu:682-695
+                if (COUNT) c_den++;
+                f3 sc             = f3{sigma_c, sigma_c, sigma_c};
+                f3 sigma_t_den    = sig_t * den - sc;
+                f3 sigma_s_den    = sig_s * den - sc;
+                f3 sigma_null_den = f3{sigma_t_prime, sigma_t_prime, sigma_t_prime} - sigma_t_den;
+                // history-aware collision probabilities kernel.cu:2112-2134 (quirk Q8)
+                float Ps = __builtin_fabsf(sigma_t_den.x * thr.x) + __builtin_fabsf(sigma_t_den.y * thr.y) +
+                           __builtin_fabsf(sigma_t_den.z * thr.z);
+                float Pn = __builtin_fabsf(sigma_null_den.x * thr.x) + __builtin_fabsf(sigma_null_den.y * thr.y) +
+                           __builtin_fabsf(sigma_null_den.z * thr.z);
+                float c = Ps + Pn;
+                float e = rng.next() * c;
+                if (e < Ps)
+                {
+                    thr         = thr * (sigma_s_den * (inv_sigma_t * c / Ps));
+                    scatter_now = true;
+                }
+                else
+                    thr = thr * (sigma_null_den * (inv_sigma_t * c / Pn));
+            }
+        }
+        else if (st == ST_SHADOW)
+        {
+            // Tr_spectral kernel.cu:782-806
+            dist += -logf_(rng.next()) * s_inv_sigma;
+            if (dist >= s_max_t || terms == 7)
+            {
+                nee_a    = f3{(float)(1 - (terms & 1)), (float)(1 - ((terms >> 1) & 1)), (float)(1 - ((terms >> 2) & 1))};
+                nee_done = true;
+            }
+            else
+            {
+                f3    sp  = pos + sd * dist;
+                float e   = rng.next();
+                float den = sample_density01<QUANT>(S, sp) * s_density;
+                if (COUNT) c_den++;
+                if (!(terms & 1) && e < sig_t.x * den * s_inv_sigma) terms |= 1;
+                if (!(terms & 2) && e < sig_t.y * den * s_inv_sigma) terms |= 2;
+                if (!(terms & 4) && e < sig_t.z * den * s_inv_sigma) terms |= 4;
+            }
+        }
+
+        // ------------------------------------------------ scatter event: direct lighting set-up
+        if (scatter_now)
+        {
+            if (COUNT) c_sca++;
+            int n_after = (EST == EST_DECOMP) ? (nsc + 1) : nsc;  // num_scatters already incremented (kernel.cu:2146,2167)
+            if (EST == EST_DECOMP) nsc = n_after;
+            // "to match passive result": hyperion with the post-increment count (DECOMP :2168) / i-4 (GLOBAL :1465)
+            float s2 = hyperion_s((EST == EST_DECOMP) ? (n_after - 5) : (nsc - 4));
+            float dp2, stp2;
+            if (EST == EST_DECOMP)
+            {
+                float reduction2 = (1.0f - s2) + s2 * (1.0f - P.g);
+                dp2              = reduction2 * density;
+                stp2             = max_sig * dp2 * d_max;  // quirk Q4: local majorant for the whole shadow ray
+            }
+            else
+            {
+                dp2  = (1.0f - s2) * density + s2 * density * (1.0f - P.g);
+                stp2 = max_sig * dp2;
+            }
+            s_inv_sigma = 1.0f / stp2;
+            s_density   = dp2;
+            ph          = hg_eval(phase_g, dot(d, sun_dir));
+            if (EST == EST_DECOMP && frame > 10 && nsc > 20)
+            {
+                // precomputed optical depth kernel.cu:2183-2189 (quirk Q5)
+                float op  = sample_float_volume(S, S.opacity, pos);
+                if (COUNT) c_opa++;
+                f3    tau = (f3{-sig_t.x, -sig_t.y, -sig_t.z} * dp2) * op;
+                nee_a     = f3{expf_(tau.x), expf_(tau.y), expf_(tau.z)};
+                nee_done  = true;
+            }
+            else
+            {
+                f3    end = sun_dir * 1e10f;
+                sd        = normalize(end - pos);
+                float tn, tf;
+                bool  hitv = intersect_box(pos, sd, S, tn, tf);
+                if (!hitv)
+                {
+                    nee_a    = f3{1.0f, 1.0f, 1.0f};
+                    nee_done = true;
+                }
+                else
+                {
+                    if (tn < 0.0f) tn = 0.0f;
+                    f3 se   = pos - end;
+                    s_max_t = fminf(tf, __builtin_sqrtf(dot(se, se)));
+                    dist    = tn;
+                    terms   = 0;
+                    st      = ST_SHADOW;
+                }
+            }
+        }
+
+        // ------------------------------------------------ NEE contribution + phase-function sampling
+        if (nee_done)
+        {
+            // radiance += sun_light_power * (throughput * phase * a)   kernel.cu:2188-2189 / :2209-2210
+            rad = rad + sun_power * ((thr * ph) * nee_a);
+            Frame fr(d);
+            float r0 = rng.next();
+            float r1 = rng.next();
+            f3    nd = normalize(fr.to_world(hg_sample_local(phase_g, r0, r1)));  // kernel.cu:2301-2303
+            o        = pos;
+            d        = nd;
+            st       = ST_SETUP;
+            if (EST == EST_GLOBAL) nsc++;
+            if (nsc >= 800) finished = true;  // max_depth kernel.cu:34, loop conditions :2015 / :1332
+        }
+
+        // ------------------------------------------------ path end: emit the sample
+        if (finished)
+        {
+            f3     r = rad * P.brightness;
+            float  heat = (EST == EST_DECOMP) ? (float)nsc : (float)((double)nsc * 0.001);  // kernel.cu:2309 / :1582
+            float4 v = make_float4(fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f), fmaxf(r.z, 0.0f), heat);
+            if (L.stage) L.stage[item] = v;
+            else
+            {
+                size_t  idx = (size_t)px + (size_t)py * P.width;
+                float4  a   = L.out[idx];
+                L.out[idx]  = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);  // kernel.cu:2315
+            }
+            st = ST_DONE;
+        }
+    }
+
+    if (COUNT)
+    {
+        // wave reduction, one atomic per counter per wave
+        unsigned long long vals[6] = {c_smp, c_den, c_bnd, c_opa, c_env, c_sca};
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+        {
+            unsigned long long v = vals[q];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) atomicAdd(&L.counters[q], v);
+        }
+    }
+}
+
+// per pixel, add the staged samples in frame order:  acc = (((acc + s0) + s1) + ...)
+__global__ __launch_bounds__(256) void reduce_stage_k(LaunchDev L)
+{
+    unsigned per_frame = L.ntiles_owned * 64u;
+    unsigned slot      = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= per_frame) return;
+    unsigned ot = slot >> 6, w = slot & 63u;
+    unsigned t  = ot * L.world + L.rank;
+    unsigned ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+    unsigned px = tx * 8u + (w & 7u), py = ty * 8u + (w >> 3);
+    if (px >= L.P.width || py >= L.P.height) return;
+    size_t idx = (size_t)px + (size_t)py * L.P.width;
+    float4 a   = L.out[idx];
+    for (int f = 0; f < L.nframes; f++)
+    {
+        float4 v = L.stage[(size_t)f * per_frame + slot];
+        a        = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
+    }
+    L.out[idx] = a;
+}
+
+// expand a dense volume into per-voxel 2x2x2 neighbourhood cells (clamped at the border)
+__global__ void pack_cells_u8_k(const unsigned char* vol, uint2* cells, int nx, int ny, int nz)
+{
+    size_t n   = (size_t)nx * ny * nz;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    int i = (int)(idx % nx), j = (int)((idx / nx) % ny), k = (int)(idx / ((size_t)nx * ny));
+    int i1 = i + 1 < nx ? i + 1 : nx - 1, j1 = j + 1 < ny ? j + 1 : ny - 1, k1 = k + 1 < nz ? k + 1 : nz - 1;
+    auto at = [&](int a, int b, int c) -> unsigned { return vol[(size_t)a + (size_t)nx * ((size_t)b + (size_t)ny * c)]; };
+    uint2 c;
+    c.x = at(i, j, k) | (at(i1, j, k) << 8) | (at(i, j1, k) << 16) | (at(i1, j1, k) << 24);
+    c.y = at(i, j, k1) | (at(i1, j, k1) << 8) | (at(i, j1, k1) << 16) | (at(i1, j1, k1) << 24);
+    cells[idx] = c;
+}
+__global__ void pack_cells_f32_k(const float* vol, float* cells, int nx, int ny, int nz)
+{
+    size_t n   = (size_t)nx * ny * nz;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    int i = (int)(idx % nx), j = (int)((idx / nx) % ny), k = (int)(idx / ((size_t)nx * ny));
+    int i1 = i + 1 < nx ? i + 1 : nx - 1, j1 = j + 1 < ny ? j + 1 : ny - 1, k1 = k + 1 < nz ? k + 1 : nz - 1;
+    auto at = [&](int a, int b, int c) -> float { return vol[(size_t)a + (size_t)nx * ((size_t)b + (size_t)ny * c)]; };
+    float4* q = reinterpret_cast<float4*>(cells) + idx * 2;
+    q[0] = make_float4(at(i, j, k), at(i1, j, k), at(i, j1, k), at(i1, j1, k));
+    q[1] = make_float4(at(i, j, k1), at(i1, j, k1), at(i, j1, k1), at(i1, j1, k1));
+}
+
+// _precompute_opacity kernel.cu:483-524 with intersect_box :453-481; one thread per voxel
+template <bool QUANT>
+__global__ __launch_bounds__(256) void opacity_k(SceneDev S, f3 light_dir, float* out)
+{
+    size_t n   = (size_t)S.nx * S.ny * S.nz;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    int i = (int)(idx % S.nx), j = (int)((idx / S.nx) % S.ny), k = (int)(idx / ((size_t)S.nx * S.ny));
+    const float dt = 0.001f;
+    f3 s0    = f3{((float)i + 0.5f) / (float)S.nx, ((float)j + 0.5f) / (float)S.ny, ((float)k + 0.5f) / (float)S.nz};
+    f3 bmin  = f3{S.bmin[0], S.bmin[1], S.bmin[2]};
+    f3 ext   = f3{S.bmax[0], S.bmax[1], S.bmax[2]} - bmin;
+    f3 start = s0 * ext + bmin;
+    float tn, tf;
+    bool  hit = intersect_box(start, light_dir, S, tn, tf);
+    if (tn <= 0.0f) tn = 0.0f;
+    float opacity = 0.0f;
+    if (hit)
+    {
+        for (float t = tn; t < tf; t += dt) opacity += sample_density01<QUANT>(S, start + light_dir * t);
+        opacity *= dt;
+    }
+    out[idx] = opacity;
+}
+
+// __scale kernel.cu:2333-2341
+__global__ void scale_k(float4* dst, const float4* src, int size, float s)
+{
+    int idx = threadIdx.x + blockIdx.x * blockDim.x;
+    if (idx >= size) return;
+    float4 v = src[idx];
+    dst[idx] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+}
+__device__ __forceinline__ float pow_pos(float x, float y) { return x <= 0.0f ? 0.0f : expf_(logf_(x) * y); }
+// __gamma_correct kernel.cu:2348-2357 (inv_gamma = 1/gamma computed by the host wrapper, :2361)
+__global__ void gamma_k(float4* dst, const float4* src, int size, float s, float inv_gamma)
+{
+    int idx = threadIdx.x + blockIdx.x * blockDim.x;
+    if (idx >= size) return;
+    float4 v = src[idx];
+    dst[idx] = make_float4(pow_pos(v.x * s, inv_gamma), pow_pos(v.y * s, inv_gamma), pow_pos(v.z * s, inv_gamma), 1.0f);
+}
+
+// ---- test kernels
+__global__ void test_math_k(int which, const float* in, float* out, int n)
+{
+    int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i >= n) return;
+    float x = in[i], s, c, r;
+    switch (which)
+    {
+        case 0: r = logf_(x); break;
+        case 1: r = expf_(x); break;
+        case 2: sincosf_(x, s, c); r = s; break;
+        case 3: sincosf_(x, s, c); r = c; break;
+        case 4: r = acosf_(x); break;
+        case 5: r = atanf_(x); break;
+        default: r = pow15f_(x); break;
+    }
+    out[i] = r;
+}
+template <class RNG>
+__global__ void test_rng_k(unsigned x, unsigned y, unsigned frame, unsigned k0, unsigned k1, int n, float* out)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    RNG r;
+    r.init(x, y, frame, k0, k1);
+    for (int i = 0; i < n; i++) out[i] = r.next();
+}
+template <bool QUANT>
+__global__ void test_density_k(SceneDev S, const float* pos, float* out, int n)
+{
+    int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i >= n) return;
+    out[i] = sample_density01<QUANT>(S, f3{pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]});
+}
+
+// ------------------------------------------------------------------ host-side launchers
+template <int EST, class RNG>
+static void launch_render2(const SceneDev& S, const LaunchDev& L, bool quant, bool count, int blocks, hipStream_t st)
+{
+    if (quant)
+    {
+        if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, true, false>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+    }
+    else
+    {
+        if (count) hipLaunchKernelGGL((render_k<EST, RNG, false, true>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, false, false>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+    }
+}
+
+void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int blocks, hipStream_t st)
+{
+    if (est == EST_DECOMP)
+    {
+        if (rng == RNG_PHILOX) launch_render2<EST_DECOMP, RngPhilox>(S, L, quant, count, blocks, st);
+        else launch_render2<EST_DECOMP, RngSamplerH>(S, L, quant, count, blocks, st);
+    }
+    else
+    {
+        if (rng == RNG_PHILOX) launch_render2<EST_GLOBAL, RngPhilox>(S, L, quant, count, blocks, st);
+        else launch_render2<EST_GLOBAL, RngSamplerH>(S, L, quant, count, blocks, st);
+    }
+}
+void launch_reduce(const LaunchDev& L, hipStream_t st)
+{
+    unsigned per_frame = L.ntiles_owned * 64u;
+    hipLaunchKernelGGL(reduce_stage_k, dim3((per_frame + 255) / 256), dim3(256), 0, st, L);
+}
+void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, hipStream_t st)
+{
+    size_t n = (size_t)nx * ny * nz;
+    hipLaunchKernelGGL(pack_cells_u8_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vol, cells, nx, ny, nz);
+}
+void launch_pack_f32(const float* vol, float* cells, int nx, int ny, int nz, hipStream_t st)
+{
+    size_t n = (size_t)nx * ny * nz;
+    hipLaunchKernelGGL(pack_cells_f32_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vol, cells, nx, ny, nz);
+}
+void launch_opacity(const SceneDev& S, bool quant, const float dir[3], float* out, hipStream_t st)
+{
+    size_t n = (size_t)S.nx * S.ny * S.nz;
+    f3     d = f3{dir[0], dir[1], dir[2]};
+    dim3   g((unsigned)((n + 255) / 256));
+    if (quant) hipLaunchKernelGGL(opacity_k<true>, g, dim3(256), 0, st, S, d, out);
+    else hipLaunchKernelGGL(opacity_k<false>, g, dim3(256), 0, st, S, d, out);
+}
+void launch_scale(float4* dst, const float4* src, int size, float s, hipStream_t st)
+{
+    hipLaunchKernelGGL(scale_k, dim3((size + 255) / 256), dim3(256), 0, st, dst, src, size, s);
+}
+void launch_gamma(float4* dst, const float4* src, int size, float s, float inv_gamma, hipStream_t st)
+{
+    hipLaunchKernelGGL(gamma_k, dim3((size + 255) / 256), dim3(256), 0, st, dst, src, size, s, inv_gamma);
+}
+void launch_test_math(int which, const float* in, float* out, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(test_math_k, dim3((n + 255) / 256), dim3(256), 0, st, which, in, out, n);
+}
+void launch_test_rng(int mode, unsigned x, unsigned y, unsigned f, unsigned k0, unsigned k1, int n, float* out, hipStream_t st)
+{
+    if (mode == RNG_PHILOX) hipLaunchKernelGGL(test_rng_k<RngPhilox>, dim3(1), dim3(64), 0, st, x, y, f, k0, k1, n, out);
+    else hipLaunchKernelGGL(test_rng_k<RngSamplerH>, dim3(1), dim3(64), 0, st, x, y, f, k0, k1, n, out);
+}
+void launch_test_density(const SceneDev& S, bool quant, const float* pos, float* out, int n, hipStream_t st)
+{
+    if (quant) hipLaunchKernelGGL(test_density_k<true>, dim3((n + 255) / 256), dim3(256), 0, st, S, pos, out, n);
+    else hipLaunchKernelGGL(test_density_k<false>, dim3((n + 255) / 256), dim3(256), 0, st, S, pos, out, n);
+}
+}  // namespace vp

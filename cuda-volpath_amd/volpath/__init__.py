@@ -1,0 +1,306 @@
+"""ctypes binding of libvolpath_hip.so (include/volpath.h).
+
+This is the host-side mirror of the reference's kernel-TU interface (src/volumeRender.cpp:117-128,
+:347-356): the same entry points under the same names, called the way the reference host calls
+them.  Everything here runs on the GPU through the C ABI; there is no CPU fallback -- if the
+library or a gfx950 device is missing the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvolpath_hip.so")
+
+EST_GLOBAL, EST_DECOMP = 0, 1
+RNG_SAMPLERH, RNG_PHILOX = 0, 1
+
+# every symbol include/volpath.h declares (tests check the library exports each one)
+PART1_SYMBOLS = ["init_cuda", "set_texture_filter_mode", "free_cuda_buffers", "precompute_opacity", "init_envmap",
+                 "free_envmap", "set_sun", "copy_inv_view_matrix", "copy_inv_model_matrix", "init_rng", "free_rng",
+                 "render_kernel", "scale", "gamma_correct"]
+PART2_SYMBOLS = ["vp_last_error", "vp_version", "vp_device_count", "vp_set_device", "vp_set_stream", "vp_synchronize",
+                 "vp_set_estimator", "vp_set_rng", "vp_set_bound_brick", "vp_set_shard", "vp_render_frames",
+                 "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity",
+                 "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_malloc", "vp_free", "vp_memset",
+                 "vp_upload", "vp_download"]
+
+
+class Float3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Dim3(C.Structure):
+    _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("z", C.c_uint32)]
+
+
+class Extent(C.Structure):
+    _fields_ = [("width", C.c_size_t), ("height", C.c_size_t), ("depth", C.c_size_t)]
+
+
+class Param(C.Structure):
+    """src/param.h:4-12"""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("density", C.c_float), ("brightness", C.c_float),
+                ("albedo", Float3), ("g", C.c_float), ("sigma_t", Float3)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "density_lookups", "density_loads", "bound_lookups",
+                                          "opacity_lookups", "env_lookups", "scatters", "rng_draws")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class VolpathError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (no GPU is touched until the first call that needs one)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VolpathError(f"{LIB_PATH} is missing: run `make -C cuda-volpath_amd` (or __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        L.vp_last_error.restype = C.c_char_p
+        L.vp_version.restype = C.c_char_p
+        L.vp_malloc.restype = C.c_void_p
+        L.vp_malloc.argtypes = [C.c_size_t]
+        L.vp_free.argtypes = [C.c_void_p]
+        L.vp_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        L.vp_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.vp_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.vp_set_stream.argtypes = [C.c_void_p]
+        L.vp_set_rng.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+        L.vp_render_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Param)]
+        L.vp_read_counters.argtypes = [C.POINTER(Counters), C.c_int]
+        L.vp_render_time_ms.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]
+        L.vp_get_bound_table.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 5
+        L.vp_get_opacity.argtypes = [C.c_void_p, C.c_size_t]
+        L.vp_test_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.vp_test_rng.argtypes = [C.c_int] + [C.c_uint32] * 5 + [C.c_int, C.c_void_p]
+        L.vp_test_sample_density.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.init_cuda.argtypes = [C.c_void_p, Extent, C.c_bool, C.POINTER(Float3), C.POINTER(Float3)]
+        L.init_cuda.restype = None
+        L.set_texture_filter_mode.argtypes = [C.c_bool]
+        L.precompute_opacity.argtypes = [C.POINTER(C.c_float)]
+        L.init_envmap.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.set_sun.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.copy_inv_view_matrix.argtypes = [C.POINTER(C.c_float), C.c_size_t]
+        L.copy_inv_model_matrix.argtypes = [C.POINTER(C.c_float), C.c_size_t]
+        L.init_rng.argtypes = [Dim3, Dim3, C.c_int, C.c_int]
+        L.render_kernel.argtypes = [Dim3, Dim3, C.c_void_p, C.c_int, C.POINTER(Param)]
+        L.scale.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+        L.gamma_correct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float]
+        for name in ("set_texture_filter_mode", "free_cuda_buffers", "precompute_opacity", "init_envmap",
+                     "free_envmap", "set_sun", "copy_inv_view_matrix", "copy_inv_model_matrix", "init_rng",
+                     "free_rng", "render_kernel", "scale", "gamma_correct"):
+            getattr(L, name).restype = None
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise VolpathError(f"volpath error {rc}: {lib().vp_last_error().decode()}")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return lib().vp_device_count()
+
+
+def make_param(width, height, density=800.0, g=0.877, brightness=1.0, albedo=(1, 1, 1), sigma_t=(1, 1, 1)):
+    """host.cpp:1286-1292 defaults with preset #13 (host.cpp:1308)."""
+    P = Param()
+    P.width, P.height, P.density, P.brightness, P.g = width, height, density, brightness, g
+    P.albedo = Float3(*albedo)
+    P.sigma_t = Float3(*sigma_t)
+    return P
+
+
+def mat(P, X, Y, Z, R, G, B):
+    """Mat(), host.cpp:44-57: sigma_s, sigma_a -> sigma_t normalised by its max, albedo = sigma_s/sigma_t."""
+    f = np.float32
+    st = [f(X) + f(R), f(Y) + f(G), f(Z) + f(B)]
+    al = [f(X) / st[0], f(Y) / st[1], f(Z) / st[2]]
+    m = max(st)
+    st = [s / m for s in st]
+    P.albedo = Float3(*[float(a) for a in al])
+    P.sigma_t = Float3(*[float(s) for s in st])
+    return P
+
+
+# H4: the default camera of the reference (host.cpp:108-115 through lookAt/inverse/transpose, :617-623)
+DEFAULT_CAMERA = (0.0, 0.207912, 0.978148, 3.922986, 0.0, 0.978148, -0.207912, -0.782739, -1.0, 0.0, 0.0, 0.03)
+
+
+class DeviceBuffer:
+    """A caller-owned float4 accumulator in HBM (CudaFrameBuffer, host.cpp:358-389)."""
+
+    def __init__(self, width, height):
+        self.width, self.height = width, height
+        self.nbytes = width * height * 16
+        self.ptr = lib().vp_malloc(self.nbytes)
+        if not self.ptr:
+            raise VolpathError(lib().vp_last_error().decode())
+        self.reset()
+
+    def reset(self):
+        _chk(lib().vp_memset(self.ptr, 0, self.nbytes))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr, np.float32)
+        assert arr.nbytes == self.nbytes
+        _chk(lib().vp_upload(self.ptr, _p(arr), self.nbytes))
+
+    def download(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        _chk(lib().vp_download(_p(out), self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().vp_free(self.ptr)
+            self.ptr = None
+
+
+def set_device(i):
+    _chk(lib().vp_set_device(i))
+
+
+def set_stream(stream_ptr):
+    _chk(lib().vp_set_stream(stream_ptr))
+
+
+def synchronize():
+    _chk(lib().vp_synchronize())
+
+
+def init_volume(grid, box=None, brick=1, linear=True):
+    """init_cuda + set_texture_filter_mode as host.cpp:1336-1344 calls them. grid[k][j][i], uint8 or float32."""
+    L = lib()
+    grid = np.ascontiguousarray(grid)
+    quantized = grid.dtype == np.uint8
+    if not quantized:
+        grid = np.ascontiguousarray(grid, np.float32)
+    nz, ny, nx = grid.shape
+    _chk(L.vp_set_bound_brick(brick))
+    ext = Extent(nx, ny, nz)
+    if box is None:
+        L.init_cuda(_p(grid), ext, quantized, None, None)
+    else:
+        L.init_cuda(_p(grid), ext, quantized, C.byref(Float3(*box[0])), C.byref(Float3(*box[1])))
+    L.set_texture_filter_mode(bool(linear))
+
+
+def init_envmap(env):
+    env = np.ascontiguousarray(env, np.float32)
+    h, w = env.shape[:2]
+    lib().init_envmap(_p(env), w, h)
+
+
+def set_sun(direction, power):
+    d = (C.c_float * 3)(*direction)
+    p = (C.c_float * 3)(*power)
+    lib().set_sun(d, p)
+
+
+def set_camera(m=DEFAULT_CAMERA):
+    a = (C.c_float * 12)(*m)
+    lib().copy_inv_view_matrix(a, 48)
+
+
+def precompute_opacity(direction):
+    d = (C.c_float * 3)(*direction)
+    lib().precompute_opacity(d)
+
+
+def set_estimator(est):
+    _chk(lib().vp_set_estimator(est))
+
+
+def set_rng(mode, key=(0, 0)):
+    _chk(lib().vp_set_rng(mode, key[0], key[1]))
+
+
+def set_shard(rank, world):
+    _chk(lib().vp_set_shard(rank, world))
+
+
+def render_kernel(buf_ptr, spp, P):
+    """The reference's per-frame call (host.cpp:631): one sample per pixel of frame `spp`."""
+    g = Dim3((P.width + 7) // 8, (P.height + 7) // 8, 1)
+    b = Dim3(8, 8, 1)
+    lib().render_kernel(g, b, buf_ptr, spp, C.byref(P))
+
+
+def render_frames(buf_ptr, first, n, P):
+    _chk(lib().vp_render_frames(buf_ptr, first, n, C.byref(P)))
+
+
+def enable_counters(on=True):
+    _chk(lib().vp_enable_counters(int(on)))
+
+
+def read_counters(reset=True):
+    c = Counters()
+    _chk(lib().vp_read_counters(C.byref(c), int(reset)))
+    return c.as_dict()
+
+
+def render_time_ms(reset=True):
+    t = C.c_double()
+    n = C.c_int()
+    _chk(lib().vp_render_time_ms(C.byref(t), C.byref(n), int(reset)))
+    return t.value, n.value
+
+
+def bound_table(quantized=True):
+    bnx, bny, bnz, brick, radius = (C.c_int() for _ in range(5))
+    _chk(lib().vp_get_bound_table(None, 0, bnx, bny, bnz, brick, radius))
+    out = np.empty((bnz.value, bny.value, bnx.value, 2), np.uint8 if quantized else np.float32)
+    _chk(lib().vp_get_bound_table(_p(out), out.nbytes, bnx, bny, bnz, brick, radius))
+    return out, brick.value, radius.value
+
+
+def opacity_table(shape):
+    out = np.empty(shape, np.float32)
+    _chk(lib().vp_get_opacity(_p(out), out.size))
+    return out
+
+
+def test_math(which, x):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    _chk(lib().vp_test_math(which, _p(x), _p(out), x.size))
+    return out
+
+
+def test_rng(mode, x, y, frame, n, key=(0, 0)):
+    out = np.empty(n, np.float32)
+    _chk(lib().vp_test_rng(mode, x, y, frame, key[0], key[1], n, _p(out)))
+    return out
+
+
+def test_sample_density(pos):
+    pos = np.ascontiguousarray(pos, np.float32)
+    out = np.empty(pos.shape[0], np.float32)
+    _chk(lib().vp_test_sample_density(_p(pos), _p(out), pos.shape[0]))
+    return out
+
+
+def scale(dst_ptr, src_ptr, n, s):
+    lib().scale(dst_ptr, src_ptr, n, s)
+
+
+def gamma_correct(dst_ptr, src_ptr, n, s, gamma):
+    lib().gamma_correct(dst_ptr, src_ptr, n, s, gamma)

@@ -1,0 +1,166 @@
+/* volpath.h -- C ABI of libvolpath_hip.so: the MI355X-native replacement for the device
+ * translation unit of RNG65536/CUDA-volpath (src/volumeRender_kernel.cu).
+ *
+ * Part 1 re-exports, under their original names, the 14 extern "C" entry points the reference
+ * host binds (src/volumeRender.cpp:117-128 and :347-356); a maintainer swaps the CUDA TU for this
+ * library and relinks.  Part 2 is additive: batched rendering, estimator / RNG
+ * selection, pixel-tile sharding for multi-GPU, counters, and raw device-memory helpers so that a
+ * C / ctypes caller needs no other GPU runtime binding.
+ *
+ * Only plain C types cross the boundary.  The CUDA vector types of the reference map onto the
+ * layout-identical PODs below (float3 = 3 floats, float4 = 4 floats 16-byte aligned,
+ * dim3 = 3 x uint32, cudaExtent = 3 x size_t).
+ *
+ * Error behaviour: Part 1 functions return void and, exactly like the reference
+ * (checkCudaErrors -> exit(EXIT_FAILURE), src/cuda/helper_cuda.h:566-579; null volume -> exit(1),
+ * kernel.cu:360-364), print a diagnostic and exit the process on failure.  Part 2 functions
+ * return 0 on success or a negative VP_E* code and leave a message in vp_last_error().
+ * There is NO CPU fallback anywhere: without a usable gfx950 device every entry point fails.
+ */
+#ifndef VOLPATH_H
+#define VOLPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, z; } vp_float3;
+typedef struct { float x, y, z, w; } vp_float4;
+typedef struct { uint32_t x, y, z; } vp_dim3;
+typedef struct { size_t width, height, depth; } vp_extent;
+
+/* src/param.h:4-12 -- 44 bytes, passed by value to the reference kernels */
+#ifndef VOLPATH_PARAM_DEFINED
+#define VOLPATH_PARAM_DEFINED
+typedef struct Param
+{
+    unsigned int width, height;
+    float        density, brightness;
+    vp_float3    albedo;
+    float        g;
+    vp_float3    sigma_t;
+} Param;
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Part 1: the reference's kernel-TU interface
+ * ------------------------------------------------------------------------------------------ */
+
+/* kernel.cu:354-420 (declared host.cpp:349-353).  Uploads the density volume (uchar if
+ * `quantized`, else float; x fastest), builds the local (max,min) bound table (replaces the
+ * call-back into host.cpp:1269-1280) and publishes the descriptors.  boxmin/boxmax may be NULL
+ * (box = +-(1, Ny/Nx, Nz/Nx)).  Caller keeps ownership of h_volume.  NULL volume -> exit(1). */
+void init_cuda(void* h_volume, vp_extent volumeSize, bool quantized, const vp_float3* boxmin,
+               const vp_float3* boxmax);
+/* kernel.cu:422-439 (host.cpp:354): point / trilinear density sampling */
+void set_texture_filter_mode(bool bLinearFilter);
+/* kernel.cu:441-451 (host.cpp:355) */
+void free_cuda_buffers(void);
+/* kernel.cu:526-553 (host.cpp:128): optical depth toward light_dir[3], dt = 0.001 */
+void precompute_opacity(const float* light_dir);
+/* kernel.cu:1072-1229 (host.cpp:125): row-major float4 lat-long map, row 0 = zenith; copied */
+void init_envmap(const vp_float4* HDRmap, int width, int height);
+/* kernel.cu:1231-1250 (host.cpp:126) */
+void free_envmap(void);
+/* kernel.cu:1269-1283 (host.cpp:127): dir[3], disc radiance power[3] */
+void set_sun(float* sun_dir, float* sun_power);
+/* kernel.cu:2320-2328 (host.cpp:119-120): row-major 3x4, sizeofMatrix = 48 */
+void copy_inv_view_matrix(float* invViewMatrix, size_t sizeofMatrix);
+void copy_inv_model_matrix(float* invModelMatrix, size_t sizeofMatrix);
+/* kernel.cu:2330-2331 (host.cpp:121-122): no-ops in the reference, no-ops here */
+void init_rng(vp_dim3 gridSize, vp_dim3 blockSize, int width, int height);
+void free_rng(void);
+/* kernel.cu:2364-2370 (host.cpp:117-118): adds ONE sample per pixel of frame `spp` into the
+ * caller-owned device buffer d_output[width*height]; asynchronous on the library stream.
+ * gridSize/blockSize are accepted for signature compatibility and ignored (the launch shape is
+ * the library's business).  In C++ the last parameter is `const Param&`, same ABI. */
+#ifdef __cplusplus
+void render_kernel(vp_dim3 gridSize, vp_dim3 blockSize, vp_float4* d_output, int spp, const Param& p);
+#else
+void render_kernel(vp_dim3 gridSize, vp_dim3 blockSize, vp_float4* d_output, int spp, const Param* p);
+#endif
+/* kernel.cu:2333-2346 / :2348-2362 (host.cpp:123-124): device pointers, in place allowed */
+void scale(vp_float4* dst, vp_float4* src, int size, float scale);
+void gamma_correct(vp_float4* dst, vp_float4* src, int size, float scale, float gamma);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 2: additive interface
+ * ------------------------------------------------------------------------------------------ */
+enum
+{
+    VP_OK          = 0,
+    VP_E_NODEVICE  = -1, /* no gfx950 device / HIP runtime error */
+    VP_E_STATE     = -2, /* call order (e.g. render before init_cuda / init_envmap) */
+    VP_E_ARG       = -3,
+    VP_E_NOOPACITY = -4  /* frame > 10 with the decomposition estimator needs precompute_opacity */
+};
+
+enum { VP_EST_GLOBAL = 0, /* __d_render, kernel.cu:1285-1591: global majorant (BASELINE config 2) */
+       VP_EST_DECOMP = 1  /* __d_render_bounded_decomp, kernel.cu:1958-2318: the reference's live kernel */ };
+enum { VP_RNG_SAMPLERH = 0, /* src/sampler.h bit-compatible streams (parity mode) */
+       VP_RNG_PHILOX   = 1  /* Philox4x32-10, counter = (x, y, frame, draw/4) */ };
+
+const char* vp_last_error(void);
+const char* vp_version(void);
+int  vp_device_count(void);
+int  vp_set_device(int device);       /* before any other call; default 0 */
+int  vp_set_stream(void* hip_stream); /* hipStream_t to launch on; NULL = library-owned stream */
+int  vp_synchronize(void);
+
+int vp_set_estimator(int est);                         /* default VP_EST_DECOMP */
+int vp_set_rng(int mode, uint32_t key0, uint32_t key1); /* default VP_RNG_SAMPLERH */
+/* brick edge (power of two, 1 = the reference's per-voxel table) used by the NEXT init_cuda */
+int vp_set_bound_brick(int brick);
+/* pixel-tile sharding: this process renders the 8x8 tiles t with t % world == rank */
+int vp_set_shard(int rank, int world);
+
+/* Adds frames [first_frame, first_frame + n_frames) into d_output[width*height] (device).
+ * Per pixel the samples are added in frame order, so the result equals n_frames successive
+ * render_kernel calls bit for bit.  Asynchronous. */
+int vp_render_frames(vp_float4* d_output, int first_frame, int n_frames, const Param* p);
+
+typedef struct
+{
+    uint64_t samples;
+    uint64_t density_lookups; /* trilinear density evaluations of the estimator */
+    uint64_t density_loads;   /* of those, the ones that issued a global load */
+    uint64_t bound_lookups;
+    uint64_t opacity_lookups;
+    uint64_t env_lookups;
+    uint64_t scatters;
+    uint64_t rng_draws;
+} vp_counters;
+/* counters are collected only while enabled (a separately compiled kernel variant) */
+int vp_enable_counters(int on);
+int vp_read_counters(vp_counters* out, int reset); /* synchronises */
+
+/* kernel time of the render launches since the last reset, measured with HIP events on the
+ * launch stream; synchronises */
+int vp_render_time_ms(double* total_ms, int* launches, int reset);
+
+/* the derived tables, for tests: bound table dims/brick and a device->host copy */
+int vp_get_bound_table(void* dst, size_t bytes, int* bnx, int* bny, int* bnz, int* brick, int* radius);
+int vp_get_opacity(float* dst, size_t count);
+
+/* building blocks exposed for parity tests (device execution, host arrays) */
+int vp_test_math(int which, const float* in, float* out, int n);
+int vp_test_rng(int mode, uint32_t x, uint32_t y, uint32_t frame, uint32_t k0, uint32_t k1, int n, float* out);
+int vp_test_sample_density(const float* pos_xyz, float* out, int n);
+
+/* raw device memory helpers */
+void* vp_malloc(size_t bytes);
+int   vp_free(void* dptr);
+int   vp_memset(void* dptr, int value, size_t bytes);
+int   vp_upload(void* dptr, const void* src, size_t bytes);
+int   vp_download(void* dst, const void* dptr, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLPATH_H */

@@ -1,0 +1,133 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on identical seeds.
+
+Bar: BIT-EXACT float4 accumulators (both sides evaluate the same binary32 operation sequences;
+see DESIGN.md "Arithmetic contract").  tolerance = 0.
+"""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+W, H = 64, 48
+
+
+def _setup(vp, oracle, grid, est, rng_mode, brick, P_kw=None, preset=None, linear=True, key=(0, 0)):
+    env = scenes.synthetic_env()
+    osc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, brick=brick,
+                             linear=linear, estimator=est, rng_mode=rng_mode, seed=key)
+    oP = oracle.default_param(W, H, **(P_kw or {}))
+    vP = vp.make_param(W, H, **(P_kw or {}))
+    if preset:
+        oracle.mat(oP, *preset)
+        vp.mat(vP, *preset)
+        assert list(oP.sigma_t) == [vP.sigma_t.x, vP.sigma_t.y, vP.sigma_t.z]
+        assert list(oP.albedo) == [vP.albedo.x, vP.albedo.y, vP.albedo.z]
+    vp.init_volume(grid, brick=brick, linear=linear)
+    vp.init_envmap(env)
+    vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+    vp.set_camera()
+    vp.set_estimator(est)
+    vp.set_rng(rng_mode, key)
+    vp.set_shard(0, 1)
+    return osc, oP, vP
+
+
+def _oracle_frames(osc, oP, frames):
+    acc = None
+    tot = None
+    for f in frames:
+        acc, c = osc.render_frame(oP, f, acc)
+        d = c.as_dict()
+        tot = d if tot is None else {k: tot[k] + d[k] for k in d}
+    return acc, tot
+
+
+@pytest.mark.parametrize("est", [1, 0])
+@pytest.mark.parametrize("rng_mode", [0, 1])
+def test_julia32_frames_bit_exact(vp, oracle, est, rng_mode):
+    grid = oracle.julia(32)
+    osc, oP, vP = _setup(vp, oracle, grid, est, rng_mode, brick=1, key=(123, 456))
+    osc.precompute_opacity()
+    vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+    # opacity table itself must agree bit for bit
+    assert np.array_equal(vp.opacity_table((32, 32, 32)), osc.opacity)
+    frames = list(range(0, 14))
+    ref, cnt = _oracle_frames(osc, oP, frames)
+    buf = vp.DeviceBuffer(W, H)
+    # (a) the reference's call pattern: one render_kernel per frame
+    for f in frames:
+        vp.render_kernel(buf.ptr, f, vP)
+    got = buf.download()
+    assert np.array_equal(got, ref), f"max abs diff {np.abs(got - ref).max()}"
+    # (b) the batched extension gives the same bits
+    buf.reset()
+    vp.enable_counters(True)
+    vp.read_counters(reset=True)
+    vp.render_frames(buf.ptr, 0, len(frames), vP)
+    got2 = buf.download()
+    c = vp.read_counters()
+    vp.enable_counters(False)
+    assert np.array_equal(got2, ref)
+    for k in ("samples", "density_lookups", "bound_lookups", "opacity_lookups", "env_lookups", "scatters"):
+        assert c[k] == cnt[k], (k, c[k], cnt[k])
+    buf.free()
+
+
+@pytest.mark.parametrize("brick", [1, 8])
+def test_julia64_chromatic_bricks(vp, oracle, brick):
+    grid = oracle.julia(64)
+    osc, oP, vP = _setup(vp, oracle, grid, 1, 0, brick=brick, preset=scenes.PRESET1)
+    tab, b, r = vp.bound_table()
+    assert b == brick and r == osc.radius
+    assert np.array_equal(tab, osc.bounds)
+    ref, _ = _oracle_frames(osc, oP, range(4))
+    buf = vp.DeviceBuffer(W, H)
+    vp.render_frames(buf.ptr, 0, 4, vP)
+    assert np.array_equal(buf.download(), ref)
+    buf.free()
+
+
+@pytest.mark.parametrize("quantized", [True, False])
+@pytest.mark.parametrize("linear", [True, False])
+def test_blob_volume_filter_modes(vp, oracle, quantized, linear):
+    grid = scenes.blob_volume_u8() if quantized else scenes.blob_volume_f32()
+    osc, oP, vP = _setup(vp, oracle, grid, 1, 0, brick=1, linear=linear, P_kw=dict(density=60.0, g=0.3))
+    ref, _ = _oracle_frames(osc, oP, range(3))
+    buf = vp.DeviceBuffer(W, H)
+    vp.render_frames(buf.ptr, 0, 3, vP)
+    assert np.array_equal(buf.download(), ref)
+    buf.free()
+
+
+def test_math_and_rng_bits(vp, oracle):
+    rng = np.random.default_rng(5)
+    u = rng.random(200000).astype(np.float32)
+    cases = {0: u, 1: (-80 * u).astype(np.float32), 2: (u * 6.2831855).astype(np.float32),
+             3: (u * 6.2831855).astype(np.float32), 4: (u * 2 - 1).astype(np.float32),
+             5: np.tan((u - 0.5) * 3.1).astype(np.float32), 6: u}
+    for which, x in cases.items():
+        assert np.array_equal(vp.test_math(which, x), oracle.math_array(which, x)), which
+    assert vp.test_math(0, np.zeros(1, np.float32))[0] == -np.inf
+    for mode in (0, 1):
+        a = vp.test_rng(mode, 3, 5, 7, 64, key=(11, 22))
+        b = oracle.rng_stream(mode, 3, 5, 7, 64, key=(11, 22))
+        assert np.array_equal(a, b)
+
+
+def test_shard_union_is_bit_identical(vp, oracle):
+    """pixel-tile sharding: the per-rank accumulators add up (one non-zero + zeros) to the 1-GPU image."""
+    grid = oracle.julia(32)
+    osc, oP, vP = _setup(vp, oracle, grid, 1, 1, brick=1, key=(9, 9))
+    ref, _ = _oracle_frames(osc, oP, range(3))
+    total = np.zeros((H, W, 4), np.float32)
+    buf = vp.DeviceBuffer(W, H)
+    for rank in range(3):
+        buf.reset()
+        vp.set_shard(rank, 3)
+        vp.render_frames(buf.ptr, 0, 3, vP)
+        total += buf.download()
+    vp.set_shard(0, 1)
+    assert np.array_equal(total, ref)
+    buf.free()
