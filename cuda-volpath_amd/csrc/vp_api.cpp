@@ -130,6 +130,7 @@ int do_init_volume(const void* h_volume, vp_extent ext, bool quantized, const vp
     if (ext.width == 0 || ext.height == 0 || ext.depth == 0) return fail(VP_E_ARG, "empty volume extent");
     size_t n = ext.width * ext.height * ext.depth;
     if (n > ((size_t)1 << 32) - 1) return fail(VP_E_ARG, "volume of %zu voxels exceeds the 2^32 cell index", n);
+    if (ext.width > 4096 || ext.height > 4096 || ext.depth > 4096) return fail(VP_E_ARG, "volume edge > 4096 voxels");
     HIPCHK(hipStreamSynchronize(G.stream));
     rc = free_volume();
     if (rc) return rc;
@@ -554,6 +555,22 @@ int vp_test_sample_density(const float* pos_xyz, float* out, int n)
     HIPCHK(hipMemcpy(out, dq, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipFree(dp));
     HIPCHK(hipFree(dq));
+    return VP_OK;
+}
+
+int vp_julia_voxelize(int n, unsigned char* host_out)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n < 1 || n > 1024 || !host_out) return fail(VP_E_ARG, "bad julia grid size %d", n);
+    size_t total = (size_t)n * n * n;
+    unsigned char* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, total));
+    launch_julia(d, n, G.stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(G.stream));
+    HIPCHK(hipMemcpy(host_out, d, total, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(d));
     return VP_OK;
 }
 

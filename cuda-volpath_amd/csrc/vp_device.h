@@ -145,12 +145,11 @@ __device__ __forceinline__ f3 to_local(const SceneDev& S, f3 pos)
 // texel-centre split of one axis: cell index (clamped) and 8-bit weight in 0..256
 __device__ __forceinline__ void axis_linear(float pn, int n, int& i, int& w)
 {
-    float x  = pn * (float)n;
-    float xb = x - 0.5f;
+    float xb = fma_(pn, (float)n, -0.5f);  // the unit's own scaling: one rounding
     float fl = __builtin_floorf(xb);
     float fr = xb - fl;
     i        = (int)fl;
-    w        = (int)__builtin_floorf(fr * 256.0f + 0.5f);
+    w        = (int)fma_(fr, 256.0f, 0.5f);  // fr >= 0: truncation == round-to-nearest of fr*256
     // the packed cell of voxel i already holds the clamped (i, i+1) pair; i < 0 degenerates to texel 0
     w = i < 0 ? 0 : w;
     i = i < 0 ? 0 : i;
@@ -171,14 +170,15 @@ __device__ __forceinline__ float filter_cell_u8(uint2 c, unsigned wx, unsigned w
 {
     unsigned t000 = c.x & 0xffu, t100 = (c.x >> 8) & 0xffu, t010 = (c.x >> 16) & 0xffu, t110 = c.x >> 24;
     unsigned t001 = c.y & 0xffu, t101 = (c.y >> 8) & 0xffu, t011 = (c.y >> 16) & 0xffu, t111 = c.y >> 24;
+    // every operand is < 2^24, every result < 2^32: full-rate v_mul/mad_u32_u24
     unsigned ix   = 256u - wx, iy = 256u - wy, iz = 256u - wz;
-    unsigned x00  = t000 * ix + t100 * wx;
-    unsigned x10  = t010 * ix + t110 * wx;
-    unsigned x01  = t001 * ix + t101 * wx;
-    unsigned x11  = t011 * ix + t111 * wx;
-    unsigned y0   = x00 * iy + x10 * wy;
-    unsigned y1   = x01 * iy + x11 * wy;
-    unsigned v    = y0 * iz + y1 * wz;
+    unsigned x00  = __umul24(t000, ix) + __umul24(t100, wx);
+    unsigned x10  = __umul24(t010, ix) + __umul24(t110, wx);
+    unsigned x01  = __umul24(t001, ix) + __umul24(t101, wx);
+    unsigned x11  = __umul24(t011, ix) + __umul24(t111, wx);
+    unsigned y0   = __umul24(x00, iy) + __umul24(x10, wy);
+    unsigned y1   = __umul24(x01, iy) + __umul24(x11, wy);
+    unsigned v    = __umul24(y0, iz) + __umul24(y1, wz);
     return (float)v * VP_U8_TRI_SCALE;
 }
 
@@ -201,7 +201,8 @@ __device__ __forceinline__ float sample_density01(const SceneDev& S, f3 pos)
         k = axis_point(p.z, S.nz);
         wx = wy = wz = 0;
     }
-    size_t idx = (size_t)((unsigned)i + (unsigned)S.nx * ((unsigned)j + (unsigned)S.ny * (unsigned)k));
+    // dims <= 4096 (checked by init_cuda): 24-bit operands, 32-bit result
+    size_t idx = (size_t)((unsigned)i + __umul24((unsigned)S.nx, (unsigned)j + __umul24((unsigned)S.ny, (unsigned)k)));
     if (QUANT)
     {
         uint2 c = S.cells_u8[idx];
@@ -233,12 +234,11 @@ __device__ __forceinline__ float sample_float_volume(const SceneDev& S, const fl
 #pragma unroll
     for (int ax = 0; ax < 3; ax++)
     {
-        float x  = pn[ax] * (float)n[ax];
-        float xb = x - 0.5f;
+        float xb = fma_(pn[ax], (float)n[ax], -0.5f);
         float fl = __builtin_floorf(xb);
         float fr = xb - fl;
         int   i  = (int)fl;
-        w[ax]    = (float)(int)__builtin_floorf(fr * 256.0f + 0.5f) * (1.0f / 256.0f);
+        w[ax]    = (float)(int)fma_(fr, 256.0f, 0.5f) * (1.0f / 256.0f);
         int i0 = i < 0 ? 0 : i;     i0 = i0 > n[ax] - 1 ? n[ax] - 1 : i0;
         int i1 = i + 1 < 0 ? 0 : i + 1; i1 = i1 > n[ax] - 1 ? n[ax] - 1 : i1;
         a[ax] = i0; b[ax] = i1;

@@ -5,6 +5,15 @@
 #include "vp_device.h"
 
 #define VP_BLOCK 256
+#define VP_CHUNK 256  // samples a wave takes from the global queue per atomic
+// the inner tracking loop of a wave runs until this many lanes are parked on an event, or until
+// a parked lane has waited this many steps
+#ifndef VP_WAIT_LANES
+#define VP_WAIT_LANES 16
+#endif
+#ifndef VP_WAIT_ITERS
+#define VP_WAIT_ITERS 32
+#endif
 
 namespace vp
 {
@@ -32,6 +41,7 @@ void launch_reduce(const LaunchDev& L, hipStream_t st);
 void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, hipStream_t st);
 void launch_pack_f32(const float* vol, float* cells, int nx, int ny, int nz, hipStream_t st);
 void launch_opacity(const SceneDev& S, bool quant, const float dir[3], float* out, hipStream_t st);
+void launch_julia(unsigned char* grid, int n, hipStream_t st);
 void launch_scale(float4* dst, const float4* src, int size, float s, hipStream_t st);
 void launch_gamma(float4* dst, const float4* src, int size, float s, float inv_gamma, hipStream_t st);
 void launch_test_math(int which, const float* in, float* out, int n, hipStream_t st);

@@ -15,7 +15,19 @@
 
 namespace vp
 {
-enum : int { ST_DONE = 0, ST_SETUP = 1, ST_TRACK = 2, ST_SHADOW = 3 };
+// per-lane path states.  FAST states advance inside the inner tracking loop; the others are events
+// a lane parks in until the wave runs its slow path.
+enum : int
+{
+    ST_DONE    = 0,  // no path: wants a new sample from the queue
+    ST_SETUP   = 1,  // needs a segment set-up (FAST for the decomposition estimator)
+    ST_TRACK   = 2,  // FAST: free-flight steps of the primary ray
+    ST_SHADOW  = 3,  // FAST: free-flight steps of the sun shadow ray (Tr_spectral)
+    EV_SCATTER = 4,  // collision found: direct-lighting set-up
+    EV_NEE     = 5,  // shadow transmittance known: add sun light, sample the phase function
+    EV_BG      = 6,  // ray left the medium: environment lookup
+    EV_WRITE   = 7   // path finished: emit the sample
+};
 
 __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
 {
@@ -37,115 +49,248 @@ __global__ __launch_bounds__(VP_BLOCK) void render_k(SceneDev S, LaunchDev L)
     // ---- per-lane path state
     int      st = ST_DONE;
     bool     exhausted = false;
-    unsigned item = 0;          // queue index of the sample this lane works on
+    unsigned item = 0;           // queue index of the sample this lane works on
     unsigned px = 0, py = 0;
     int      frame = 0;
     RNG      rng;
-    f3       o = {}, d = {};     // primary ray
+    f3       ro = {}, rd = {};   // the ray being tracked (primary, or the shadow ray while ST_SHADOW)
+    f3       pd = {};            // primary direction, kept while the shadow ray is tracked
     f3       thr = {}, rad = {};
     int      nsc = 0;            // num_scatters (DECOMP) / depth i (GLOBAL)
-    // segment (primary tracking)
-    float t_far = 0, dist = 0, distc = 0, inv_sigma = 0, inv_sigma_t = 0, sigma_t_prime = 0, sigma_c = 0;
-    float density_prime = 0, d_max = 0, phase_g = 0;
-    // scatter point + shadow ray
-    f3    pos = {}, sd = {};
-    float s_max_t = 0, s_inv_sigma = 0, s_density = 0, ph = 0;
-    int   terms = 0;
+    float    dist = 0, t_end = 0;  // position on the tracked ray; where the current free flight ends
+    float    t_far = 0, distc = 0, inv_sigma = 0, inv_sigma_t = 0, sigma_t_prime = 0, sigma_c = 0;
+    float    cur_density = 0, d_max = 0, phase_g = 0, ph = 0;
+    f3       nee_a = {};
+    int      terms = 0;
 
     unsigned long long c_den = 0, c_bnd = 0, c_opa = 0, c_env = 0, c_sca = 0, c_smp = 0;
 
     const unsigned lane = threadIdx.x & 63u;
+    unsigned chunk_next = 0, chunk_end = 0;  // wave-uniform
+    bool     queue_empty = false;
 
     for (;;)
     {
-        // ------------------------------------------------ refill finished lanes from the queue
+        // =========================================================== slow path: events
+        // ---- collision: direct lighting set-up (kernel.cu:2161-2217 / :1458-1491)
+        if (st == EV_SCATTER)
         {
-            bool               need = (st == ST_DONE) && !exhausted;
-            unsigned long long m    = __ballot(need);
-            if (m)
-            {
-                unsigned cnt    = (unsigned)__popcll(m);
-                unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
-                unsigned base   = 0;
-                if (lane == leader) base = atomicAdd(L.queue, cnt);
-                base = (unsigned)__shfl((int)base, (int)leader, 64);
-                if (need)
-                {
-                    item = base + lane_rank(m);
-                    if (item >= L.total_items) exhausted = true;
-                    else
-                    {
-                        unsigned per_frame = L.ntiles_owned * 64u;
-                        unsigned fl  = item / per_frame;
-                        unsigned rem = item - fl * per_frame;
-                        unsigned ot  = rem >> 6, w = rem & 63u;
-                        unsigned t   = ot * L.world + L.rank;
-                        unsigned ty  = t / L.tiles_x, tx = t - ty * L.tiles_x;
-                        px    = tx * 8u + (w & 7u);
-                        py    = ty * 8u + (w >> 3);
-                        frame = L.frame0 + (int)fl;
-                        if (px < P.width && py < P.height)
-                        {
-                            // camera ray, kernel.cu:1977-1987 (quirk Q3)
-                            rng.init(px, py, (unsigned)frame, L.key0, L.key1);
-                            float u = ((float)px * 2.0f - (float)P.width) / (float)P.width;
-                            float v = ((float)py * 2.0f - (float)P.height) / (float)P.width;
-                            o       = f3{S.cam[3], S.cam[7], S.cam[11]};
-                            f3 dv   = f3{u, v, S.cam_z};
-                            d = normalize(f3{dot(dv, f3{S.cam[0], S.cam[1], S.cam[2]}), dot(dv, f3{S.cam[4], S.cam[5], S.cam[6]}),
-                                             dot(dv, f3{S.cam[8], S.cam[9], S.cam[10]})});
-                            thr = f3{1.0f, 1.0f, 1.0f};
-                            rad = f3{0.0f, 0.0f, 0.0f};
-                            nsc = 0;
-                            st  = ST_SETUP;
-                            if (COUNT) c_smp++;
-                        }
-                        // pixels of a partial edge tile outside the image: nothing to do, stay DONE
-                    }
-                }
-            }
-            if (__ballot(st != ST_DONE || !exhausted) == 0ull) break;
-        }
-
-        bool finished = false;  // path ended this iteration: write the sample
-
-        // ------------------------------------------------ segment set-up
-        if (st == ST_SETUP)
-        {
-            float t_near, tf;
-            bool  hit = intersect_box(o, d, S, t_near, tf);
+            if (COUNT) c_sca++;
+            if (EST == EST_DECOMP) nsc++;  // num_scatters += !through, kernel.cu:2146
+            // "to match passive result": post-increment count (DECOMP :2168) / i-4 (GLOBAL :1465)
+            float s2 = hyperion_s((EST == EST_DECOMP) ? (nsc - 5) : (nsc - 4));
+            float dp2, stp2;
             if (EST == EST_DECOMP)
             {
-                // intersectSuperVolume kernel.cu:1626-1661 (quirks Q6, Q10): the bound is fetched before the hit test
-                t_near = fmaxf(t_near, 0.0f);
-                t_far  = fminf(tf, 0.05f);
-                float bx, by;
-                sample_bound<QUANT>(S, o + d * t_near, bx, by);
-                if (COUNT) c_bnd++;
-                float d_min = by;
-                d_max       = fmaxf(0.0001f, bx);
-                if (!hit)
+                float reduction2 = (1.0f - s2) + s2 * (1.0f - P.g);
+                dp2              = reduction2 * density;
+                stp2             = max_sig * dp2 * d_max;  // quirk Q4: the local majorant for the whole shadow ray
+            }
+            else
+            {
+                dp2  = (1.0f - s2) * density + s2 * density * (1.0f - P.g);
+                stp2 = max_sig * dp2;
+            }
+            ph = hg_eval(phase_g, dot(rd, sun_dir));
+            pd = rd;
+            // here ro already holds the collision point (set by the tracking step)
+            if (EST == EST_DECOMP && frame > 10 && nsc > 20)
+            {
+                // precomputed optical depth kernel.cu:2183-2189 (quirk Q5)
+                float op = sample_float_volume(S, S.opacity, ro);
+                if (COUNT) c_opa++;
+                f3 tau = (f3{-sig_t.x, -sig_t.y, -sig_t.z} * dp2) * op;
+                nee_a  = f3{expf_(tau.x), expf_(tau.y), expf_(tau.z)};
+                st     = EV_NEE;
+            }
+            else
+            {
+                // Tr_spectral set-up kernel.cu:763-780
+                f3    end = sun_dir * 1e10f;
+                f3    sd  = normalize(end - ro);
+                float tn, tf;
+                bool  hitv = intersect_box(ro, sd, S, tn, tf);
+                if (!hitv)
                 {
-                    f3 bg;
-                    if (nsc == 0 && dot(d, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
-                    else { bg = eval_envmap(S, d); if (COUNT) c_env++; }
-                    rad      = rad + bg * thr;
-                    finished = true;
+                    nee_a = f3{1.0f, 1.0f, 1.0f};
+                    st    = EV_NEE;
                 }
                 else
                 {
-                    bool use_decomp = d_min > 0.0f;
+                    if (tn < 0.0f) tn = 0.0f;
+                    f3 se       = ro - end;
+                    t_end       = fminf(tf, __builtin_sqrtf(dot(se, se)));
+                    dist        = tn;
+                    terms       = 0;
+                    rd          = sd;
+                    inv_sigma   = 1.0f / stp2;
+                    cur_density = dp2;
+                    st          = ST_SHADOW;
+                }
+            }
+        }
+        // ---- sun contribution + phase-function sampling (kernel.cu:2188-2189,:2209-2210,:2301-2303)
+        if (st == EV_NEE)
+        {
+            rad = rad + sun_power * ((thr * ph) * nee_a);
+            Frame fr(pd);
+            float r0 = rng.next();
+            float r1 = rng.next();
+            rd       = normalize(fr.to_world(hg_sample_local(phase_g, r0, r1)));
+            st       = ST_SETUP;
+            if (EST == EST_GLOBAL) nsc++;
+            if (nsc >= 800) st = EV_WRITE;  // max_depth kernel.cu:34, loop conditions :2015 / :1332
+        }
+#pragma unroll 1
+        for (int rep = 0; rep < 4; rep++)
+        {
+            // ---- refill finished lanes from the queue.  The wave owns a chunk [chunk_next, chunk_end)
+            // of consecutive samples (one atomic per VP_CHUNK samples); idle lanes are compacted
+            // with ballot + mbcnt and take the next samples of the chunk.
+            {
+                bool               need = (st == ST_DONE) && !exhausted;
+                unsigned long long m    = __ballot(need);
+                if (m)
+                {
+                    if (chunk_next >= chunk_end && !queue_empty)
+                    {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(L.queue, (unsigned)VP_CHUNK);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (base >= L.total_items) { queue_empty = true; chunk_next = chunk_end = L.total_items; }
+                        else
+                        {
+                            chunk_next = base;
+                            chunk_end  = (L.total_items - base < (unsigned)VP_CHUNK) ? L.total_items : base + (unsigned)VP_CHUNK;
+                        }
+                    }
+                    unsigned cnt   = (unsigned)__popcll(m);
+                    unsigned avail = chunk_end - chunk_next;
+                    unsigned take  = cnt < avail ? cnt : avail;
+                    unsigned rank  = lane_rank(m);
+                    if (need)
+                    {
+                        if (rank >= take) { if (queue_empty) exhausted = true; /* else: next chunk, next round */ }
+                        else
+                        {
+                            item = chunk_next + rank;
+                            unsigned per_frame = L.ntiles_owned * 64u;
+                            unsigned fl  = item / per_frame;
+                            unsigned rem = item - fl * per_frame;
+                            unsigned ot  = rem >> 6, w = rem & 63u;
+                            unsigned t   = ot * L.world + L.rank;
+                            unsigned ty  = t / L.tiles_x, tx = t - ty * L.tiles_x;
+                            px    = tx * 8u + (w & 7u);
+                            py    = ty * 8u + (w >> 3);
+                            frame = L.frame0 + (int)fl;
+                            if (px < P.width && py < P.height)
+                            {
+                                // camera ray, kernel.cu:1977-1987 (quirk Q3)
+                                rng.init(px, py, (unsigned)frame, L.key0, L.key1);
+                                float u = ((float)px * 2.0f - (float)P.width) / (float)P.width;
+                                float v = ((float)py * 2.0f - (float)P.height) / (float)P.width;
+                                ro      = f3{S.cam[3], S.cam[7], S.cam[11]};
+                                f3 dv   = f3{u, v, S.cam_z};
+                                rd = normalize(f3{dot(dv, f3{S.cam[0], S.cam[1], S.cam[2]}), dot(dv, f3{S.cam[4], S.cam[5], S.cam[6]}),
+                                                  dot(dv, f3{S.cam[8], S.cam[9], S.cam[10]})});
+                                thr = f3{1.0f, 1.0f, 1.0f};
+                                rad = f3{0.0f, 0.0f, 0.0f};
+                                nsc = 0;
+                                st  = ST_SETUP;
+                                if (COUNT) c_smp++;
+                            }
+                            // pixels of a partial edge tile outside the image: nothing to do, stay DONE
+                        }
+                    }
+                    chunk_next += take;
+                }
+            }
+            // ---- global-majorant segment set-up (__d_render kernel.cu:1332-1370); rare, so it lives here
+            if (EST == EST_GLOBAL && st == ST_SETUP)
+            {
+                float t_near, tf;
+                bool  hit = intersect_box(ro, rd, S, t_near, tf);
+                if (!hit) st = EV_BG;
+                else
+                {
+                    if (t_near < 0.0f) t_near = 0.0f;
+                    t_far         = tf;
+                    t_end         = tf;
+                    dist          = t_near;
+                    float s       = hyperion_s(nsc - 5);
+                    phase_g       = (1.0f - s) * P.g;
+                    cur_density   = (1.0f - s) * density + s * density * (1.0f - P.g);
+                    sigma_t_prime = max_sig * cur_density;
+                    inv_sigma     = 1.0f / sigma_t_prime;
+                    inv_sigma_t   = inv_sigma;
+                    st            = ST_TRACK;
+                }
+            }
+            // ---- ray left the medium: background() kernel.cu:1258-1267 (quirk Q11)
+            if (st == EV_BG)
+            {
+                f3 bg;
+                if (nsc == 0 && dot(rd, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
+                else { bg = eval_envmap(S, rd); if (COUNT) c_env++; }
+                rad = rad + bg * thr;
+                st  = EV_WRITE;
+            }
+            // ---- path end: emit the sample (kernel.cu:2306-2316 / :1579-1589)
+            if (st == EV_WRITE)
+            {
+                f3     r    = rad * P.brightness;
+                float  heat = (EST == EST_DECOMP) ? (float)nsc : (float)((double)nsc * 0.001);
+                float4 v    = make_float4(fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f), fmaxf(r.z, 0.0f), heat);
+                if (L.stage) L.stage[item] = v;
+                else
+                {
+                    size_t idx = (size_t)px + (size_t)py * P.width;
+                    float4 a   = L.out[idx];
+                    L.out[idx] = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
+                }
+                st = ST_DONE;
+            }
+            if (__ballot(st == ST_DONE && !exhausted) == 0ull) break;
+        }
+        if (__ballot(st != ST_DONE || !exhausted) == 0ull) break;  // queue drained and every lane idle
+
+        // =========================================================== fast path: tracking
+#pragma unroll 1
+        for (int iter = 0;; iter++)
+        {
+            bool active = (st == ST_TRACK) || (st == ST_SHADOW) || (EST == EST_DECOMP && st == ST_SETUP);
+            unsigned long long am = __ballot(active);
+            unsigned long long wm = __ballot(!active && !(st == ST_DONE && exhausted));
+            unsigned nwait = (unsigned)__popcll(wm);
+            if (am == 0ull || nwait >= (unsigned)VP_WAIT_LANES || (nwait > 0u && iter >= VP_WAIT_ITERS)) break;
+            if (!active) continue;
+
+            if (EST == EST_DECOMP && st == ST_SETUP)
+            {
+                // intersectSuperVolume kernel.cu:1626-1661 (quirks Q6, Q10): the bound is fetched before the hit test
+                float t_near, tf;
+                bool  hit = intersect_box(ro, rd, S, t_near, tf);
+                t_near    = fmaxf(t_near, 0.0f);
+                t_far     = fminf(tf, 0.05f);
+                float bx, by;
+                sample_bound<QUANT>(S, ro + rd * t_near, bx, by);
+                if (COUNT) c_bnd++;
+                float d_min = by;
+                d_max       = fmaxf(0.0001f, bx);
+                if (!hit) st = EV_BG;
+                else
+                {
                     dist            = t_near;
                     float s         = hyperion_s(nsc - 5);
                     phase_g         = (1.0f - s) * P.g;
                     float reduction = (1.0f - s) + s * (1.0f - P.g);
-                    density_prime   = reduction * density;
-                    sigma_t_prime   = max_sig * density_prime * d_max;
+                    cur_density     = reduction * density;
+                    sigma_t_prime   = max_sig * cur_density * d_max;
                     inv_sigma_t     = 1.0f / sigma_t_prime;
-                    if (use_decomp)
+                    if (d_min > 0.0f)
                     {
                         // analog decomposition tracking kernel.cu:2048-2054 (quirk Q7)
-                        sigma_c       = min_sig * density_prime * d_min;
+                        sigma_c       = min_sig * cur_density * d_min;
                         distc         = dist - logf_(rng.next()) / fmaxf(sigma_c, 1e-20f);
                         float sigma_r = fmaxf(sigma_t_prime - sigma_c, 1e-20f);
                         inv_sigma     = 1.0f / sigma_r;
@@ -156,203 +301,82 @@ __global__ __launch_bounds__(VP_BLOCK) void render_k(SceneDev S, LaunchDev L)
                         sigma_c   = 0.0f;
                         inv_sigma = inv_sigma_t;
                     }
-                    st = ST_TRACK;
+                    t_end = fminf(distc, t_far);  // dist >= distc || dist >= t_far  (kernel.cu:2086)
+                    st    = ST_TRACK;
                 }
             }
-            else
-            {
-                // __d_render kernel.cu:1332-1370
-                if (!hit)
-                {
-                    f3 bg;
-                    if (nsc == 0 && dot(d, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
-                    else { bg = eval_envmap(S, d); if (COUNT) c_env++; }
-                    rad      = rad + bg * thr;
-                    finished = true;
-                }
-                else
-                {
-                    if (t_near < 0.0f) t_near = 0.0f;
-                    t_far         = tf;
-                    dist          = t_near;
-                    float s       = hyperion_s(nsc - 5);
-                    phase_g       = (1.0f - s) * P.g;
-                    density_prime = (1.0f - s) * density + s * density * (1.0f - P.g);
-                    sigma_t_prime = max_sig * density_prime;
-                    inv_sigma     = 1.0f / sigma_t_prime;
-                    inv_sigma_t   = inv_sigma;
-                    sigma_c       = 0.0f;
-                    distc         = 1e20f;
-                    d_max         = 1.0f;
-                    st            = ST_TRACK;
-                }
-            }
-        }
 
-        // ------------------------------------------------ one free-flight step
-        bool scatter_now = false;  // primary ray reached a (real or control) collision
-        bool nee_done    = false;  // shadow ray finished (or NEE needed no tracking)
-        f3   nee_a       = {1.0f, 1.0f, 1.0f};
-
-        if (st == ST_TRACK)
-        {
-            dist += -logf_(rng.next()) * inv_sigma;
-            bool end = (EST == EST_DECOMP) ? (dist >= distc || dist >= t_far) : (dist >= t_far);
-            if (end)
+            if (st == ST_TRACK || st == ST_SHADOW)
             {
-                if (EST == EST_DECOMP)
+                const bool shadow = st == ST_SHADOW;
+                dist += -logf_(rng.next()) * inv_sigma;  // kernel.cu:2085 / :784
+                if (dist >= t_end || (shadow && terms == 7))
                 {
-                    pos          = o + d * distc;
-                    bool through = fminf(distc, dist) >= t_far;
-                    if (through)
+                    if (shadow)
                     {
-                        o  = o + d * t_far;  // tracking restart kernel.cu:2151-2155
-                        st = ST_SETUP;
+                        // Tr_spectral returns 1 - terminated flags (kernel.cu:807)
+                        nee_a = f3{(float)(1 - (terms & 1)), (float)(1 - ((terms >> 1) & 1)), (float)(1 - ((terms >> 2) & 1))};
+                        st    = EV_NEE;
+                    }
+                    else if (EST == EST_DECOMP)
+                    {
+                        bool through = fminf(distc, dist) >= t_far;  // kernel.cu:2145
+                        if (through)
+                        {
+                            ro = ro + rd * t_far;  // tracking restart kernel.cu:2151-2155
+                            st = ST_SETUP;
+                        }
+                        else
+                        {
+                            ro = ro + rd * distc;  // control collision kernel.cu:2088
+                            st = EV_SCATTER;
+                        }
                     }
                     else
-                        scatter_now = true;
+                        st = EV_BG;  // transmitted through the box kernel.cu:1444-1452
                 }
                 else
                 {
-                    // transmitted through the whole box: kernel.cu:1444-1452
-                    f3 bg;
-                    if (nsc == 0 && dot(d, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
-                    else { bg = eval_envmap(S, d); if (COUNT) c_env++; }
-                    rad      = rad + bg * thr;
-                    finished = true;
+                    f3    p   = ro + rd * dist;
+                    float den = sample_density01<QUANT>(S, p) * cur_density;  // vol_sigma_t kernel.cu:682-695
+                    float e   = rng.next();
+                    if (COUNT) c_den++;
+                    if (shadow)
+                    {
+                        // kernel.cu:791-805
+                        if (!(terms & 1) && e < sig_t.x * den * inv_sigma) terms |= 1;
+                        if (!(terms & 2) && e < sig_t.y * den * inv_sigma) terms |= 2;
+                        if (!(terms & 4) && e < sig_t.z * den * inv_sigma) terms |= 4;
+                    }
+                    else
+                    {
+                        // history-aware collision probabilities kernel.cu:2107-2134 (quirk Q8)
+                        f3 sigma_t_den = sig_t * den;
+                        f3 sigma_s_den = sig_s * den;
+                        if (EST == EST_DECOMP)
+                        {
+                            f3 sc       = f3{sigma_c, sigma_c, sigma_c};
+                            sigma_t_den = sigma_t_den - sc;
+                            sigma_s_den = sigma_s_den - sc;
+                        }
+                        f3    sigma_null_den = f3{sigma_t_prime, sigma_t_prime, sigma_t_prime} - sigma_t_den;
+                        float Ps = __builtin_fabsf(sigma_t_den.x * thr.x) + __builtin_fabsf(sigma_t_den.y * thr.y) +
+                                   __builtin_fabsf(sigma_t_den.z * thr.z);
+                        float Pn = __builtin_fabsf(sigma_null_den.x * thr.x) + __builtin_fabsf(sigma_null_den.y * thr.y) +
+                                   __builtin_fabsf(sigma_null_den.z * thr.z);
+                        float c    = Ps + Pn;
+                        bool  real = e * c < Ps;
+                        float f    = inv_sigma_t * c / (real ? Ps : Pn);
+                        f3    sel  = real ? sigma_s_den : sigma_null_den;
+                        thr        = thr * (sel * f);
+                        if (real)
+                        {
+                            ro = p;
+                            st = EV_SCATTER;
+                        }
+                    }
                 }
             }
-            else
-            {
-                pos       = o + d * dist;
-                float den = sample_density01<QUANT>(S, pos) * density_prime;  // vol_sigma_t kernel.cu:682-695
-                if (COUNT) c_den++;
-                f3 sc             = f3{sigma_c, sigma_c, sigma_c};
-                f3 sigma_t_den    = sig_t * den - sc;
-                f3 sigma_s_den    = sig_s * den - sc;
-                f3 sigma_null_den = f3{sigma_t_prime, sigma_t_prime, sigma_t_prime} - sigma_t_den;
-                // history-aware collision probabilities kernel.cu:2112-2134 (quirk Q8)
-                float Ps = __builtin_fabsf(sigma_t_den.x * thr.x) + __builtin_fabsf(sigma_t_den.y * thr.y) +
-                           __builtin_fabsf(sigma_t_den.z * thr.z);
-                float Pn = __builtin_fabsf(sigma_null_den.x * thr.x) + __builtin_fabsf(sigma_null_den.y * thr.y) +
-                           __builtin_fabsf(sigma_null_den.z * thr.z);
-                float c = Ps + Pn;
-                float e = rng.next() * c;
-                if (e < Ps)
-                {
-                    thr         = thr * (sigma_s_den * (inv_sigma_t * c / Ps));
-                    scatter_now = true;
-                }
-                else
-                    thr = thr * (sigma_null_den * (inv_sigma_t * c / Pn));
-            }
-        }
-        else if (st == ST_SHADOW)
-        {
-            // Tr_spectral kernel.cu:782-806
-            dist += -logf_(rng.next()) * s_inv_sigma;
-            if (dist >= s_max_t || terms == 7)
-            {
-                nee_a    = f3{(float)(1 - (terms & 1)), (float)(1 - ((terms >> 1) & 1)), (float)(1 - ((terms >> 2) & 1))};
-                nee_done = true;
-            }
-            else
-            {
-                f3    sp  = pos + sd * dist;
-                float e   = rng.next();
-                float den = sample_density01<QUANT>(S, sp) * s_density;
-                if (COUNT) c_den++;
-                if (!(terms & 1) && e < sig_t.x * den * s_inv_sigma) terms |= 1;
-                if (!(terms & 2) && e < sig_t.y * den * s_inv_sigma) terms |= 2;
-                if (!(terms & 4) && e < sig_t.z * den * s_inv_sigma) terms |= 4;
-            }
-        }
-
-        // ------------------------------------------------ scatter event: direct lighting set-up
-        if (scatter_now)
-        {
-            if (COUNT) c_sca++;
-            int n_after = (EST == EST_DECOMP) ? (nsc + 1) : nsc;  // num_scatters already incremented (kernel.cu:2146,2167)
-            if (EST == EST_DECOMP) nsc = n_after;
-            // "to match passive result": hyperion with the post-increment count (DECOMP :2168) / i-4 (GLOBAL :1465)
-            float s2 = hyperion_s((EST == EST_DECOMP) ? (n_after - 5) : (nsc - 4));
-            float dp2, stp2;
-            if (EST == EST_DECOMP)
-            {
-                float reduction2 = (1.0f - s2) + s2 * (1.0f - P.g);
-                dp2              = reduction2 * density;
-                stp2             = max_sig * dp2 * d_max;  // quirk Q4: local majorant for the whole shadow ray
-            }
-            else
-            {
-                dp2  = (1.0f - s2) * density + s2 * density * (1.0f - P.g);
-                stp2 = max_sig * dp2;
-            }
-            s_inv_sigma = 1.0f / stp2;
-            s_density   = dp2;
-            ph          = hg_eval(phase_g, dot(d, sun_dir));
-            if (EST == EST_DECOMP && frame > 10 && nsc > 20)
-            {
-                // precomputed optical depth kernel.cu:2183-2189 (quirk Q5)
-                float op  = sample_float_volume(S, S.opacity, pos);
-                if (COUNT) c_opa++;
-                f3    tau = (f3{-sig_t.x, -sig_t.y, -sig_t.z} * dp2) * op;
-                nee_a     = f3{expf_(tau.x), expf_(tau.y), expf_(tau.z)};
-                nee_done  = true;
-            }
-            else
-            {
-                f3    end = sun_dir * 1e10f;
-                sd        = normalize(end - pos);
-                float tn, tf;
-                bool  hitv = intersect_box(pos, sd, S, tn, tf);
-                if (!hitv)
-                {
-                    nee_a    = f3{1.0f, 1.0f, 1.0f};
-                    nee_done = true;
-                }
-                else
-                {
-                    if (tn < 0.0f) tn = 0.0f;
-                    f3 se   = pos - end;
-                    s_max_t = fminf(tf, __builtin_sqrtf(dot(se, se)));
-                    dist    = tn;
-                    terms   = 0;
-                    st      = ST_SHADOW;
-                }
-            }
-        }
-
-        // ------------------------------------------------ NEE contribution + phase-function sampling
-        if (nee_done)
-        {
-            // radiance += sun_light_power * (throughput * phase * a)   kernel.cu:2188-2189 / :2209-2210
-            rad = rad + sun_power * ((thr * ph) * nee_a);
-            Frame fr(d);
-            float r0 = rng.next();
-            float r1 = rng.next();
-            f3    nd = normalize(fr.to_world(hg_sample_local(phase_g, r0, r1)));  // kernel.cu:2301-2303
-            o        = pos;
-            d        = nd;
-            st       = ST_SETUP;
-            if (EST == EST_GLOBAL) nsc++;
-            if (nsc >= 800) finished = true;  // max_depth kernel.cu:34, loop conditions :2015 / :1332
-        }
-
-        // ------------------------------------------------ path end: emit the sample
-        if (finished)
-        {
-            f3     r = rad * P.brightness;
-            float  heat = (EST == EST_DECOMP) ? (float)nsc : (float)((double)nsc * 0.001);  // kernel.cu:2309 / :1582
-            float4 v = make_float4(fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f), fmaxf(r.z, 0.0f), heat);
-            if (L.stage) L.stage[item] = v;
-            else
-            {
-                size_t  idx = (size_t)px + (size_t)py * P.width;
-                float4  a   = L.out[idx];
-                L.out[idx]  = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);  // kernel.cu:2315
-            }
-            st = ST_DONE;
         }
     }
 
@@ -461,6 +485,31 @@ __global__ void gamma_k(float4* dst, const float4* src, int size, float s, float
     dst[idx] = make_float4(pow_pos(v.x * s, inv_gamma), pow_pos(v.y * s, inv_gamma), pow_pos(v.z * s, inv_gamma), 1.0f);
 }
 
+// FractalJuliaSet kernel.cu:84-140 voxelised at texel centres over [-1,1]^3:
+// q <- q^2 + c, c = (-0.2, 0.8, 0, 0), radius 1.4, maxIter 30, escape dot(q,q) >= 10, density = iter > 27
+__global__ void julia_k(unsigned char* grid, int n)
+{
+    size_t total = (size_t)n * n * n;
+    size_t idx   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int   i = (int)(idx % n), j = (int)((idx / n) % n), k = (int)(idx / ((size_t)n * n));
+    float fn = (float)n;
+    float px = ((float)i + 0.5f) / fn * 2.0f - 1.0f, py = ((float)j + 0.5f) / fn * 2.0f - 1.0f,
+          pz = ((float)k + 0.5f) / fn * 2.0f - 1.0f;
+    float qx = px * 1.4f, qy = py * 1.4f, qz = pz * 1.4f, qw = 0.0f;
+    int   iter = 0;
+    float dd;
+    do
+    {
+        float r0 = qx * qx - (qy * qy + qz * qz + qw * qw);
+        float s  = qx * 2.0f;
+        float ry = qy * s, rz = qz * s, rw = qw * s;
+        qx = r0 + -0.2f; qy = ry + 0.8f; qz = rz + 0.0f; qw = rw + 0.0f;
+        dd = qx * qx + qy * qy + qz * qz + qw * qw;
+    } while (dd < 10.0f && iter++ < 30);
+    grid[idx] = iter > 27 ? 255 : 0;
+}
+
 // ---- test kernels
 __global__ void test_math_k(int which, const float* in, float* out, int n)
 {
@@ -546,6 +595,11 @@ void launch_opacity(const SceneDev& S, bool quant, const float dir[3], float* ou
     dim3   g((unsigned)((n + 255) / 256));
     if (quant) hipLaunchKernelGGL(opacity_k<true>, g, dim3(256), 0, st, S, d, out);
     else hipLaunchKernelGGL(opacity_k<false>, g, dim3(256), 0, st, S, d, out);
+}
+void launch_julia(unsigned char* grid, int n, hipStream_t st)
+{
+    size_t total = (size_t)n * n * n;
+    hipLaunchKernelGGL(julia_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, grid, n);
 }
 void launch_scale(float4* dst, const float4* src, int size, float s, hipStream_t st)
 {

@@ -23,7 +23,7 @@ PART1_SYMBOLS = ["init_cuda", "set_texture_filter_mode", "free_cuda_buffers", "p
 PART2_SYMBOLS = ["vp_last_error", "vp_version", "vp_device_count", "vp_set_device", "vp_set_stream", "vp_synchronize",
                  "vp_set_estimator", "vp_set_rng", "vp_set_bound_brick", "vp_set_shard", "vp_render_frames",
                  "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity",
-                 "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_malloc", "vp_free", "vp_memset",
+                 "vp_julia_voxelize", "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_malloc", "vp_free", "vp_memset",
                  "vp_upload", "vp_download"]
 
 
@@ -82,6 +82,7 @@ def lib():
         L.vp_render_time_ms.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]
         L.vp_get_bound_table.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 5
         L.vp_get_opacity.argtypes = [C.c_void_p, C.c_size_t]
+        L.vp_julia_voxelize.argtypes = [C.c_int, C.c_void_p]
         L.vp_test_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.vp_test_rng.argtypes = [C.c_int] + [C.c_uint32] * 5 + [C.c_int, C.c_void_p]
         L.vp_test_sample_density.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -295,6 +296,13 @@ def test_sample_density(pos):
     pos = np.ascontiguousarray(pos, np.float32)
     out = np.empty(pos.shape[0], np.float32)
     _chk(lib().vp_test_sample_density(_p(pos), _p(out), pos.shape[0]))
+    return out
+
+
+def julia_volume(n):
+    """FractalJuliaSet (kernel.cu:84-140) voxelised on the GPU -> uint8 [k][j][i]."""
+    out = np.empty((n, n, n), np.uint8)
+    _chk(lib().vp_julia_voxelize(n, _p(out)))
     return out
 
 

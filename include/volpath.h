@@ -153,6 +153,11 @@ int vp_test_math(int which, const float* in, float* out, int n);
 int vp_test_rng(int mode, uint32_t x, uint32_t y, uint32_t frame, uint32_t k0, uint32_t k1, int n, float* out);
 int vp_test_sample_density(const float* pos_xyz, float* out, int n);
 
+/* The procedural Julia-set volume of the reference (FractalJuliaSet, kernel.cu:84-140) voxelised at
+ * texel centres over [-1,1]^3 to an n^3 uchar grid (0 / 255), x fastest; written to HOST memory so it
+ * can be handed to init_cuda like any other volume. */
+int vp_julia_voxelize(int n, unsigned char* host_out);
+
 /* raw device memory helpers */
 void* vp_malloc(size_t bytes);
 int   vp_free(void* dptr);

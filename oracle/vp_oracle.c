@@ -270,12 +270,11 @@ DEFINE_BOUNDS(vpo_bounds_f32, float)
 /* texel-centre coordinate split with 8-bit weight: returns clamped i0,i1 and w in 0..256 */
 static inline void tex_axis_linear(float pn, int n, int* i0, int* i1, int* w)
 {
-    float x  = pn * (float)n;
-    float xb = x - 0.5f;
+    float xb = fmaf(pn, (float)n, -0.5f); /* the unit's own scaling: one rounding */
     float fl = floorf(xb);
     float fr = xb - fl;
     int   i  = (int)fl;
-    *w       = (int)floorf(fr * 256.0f + 0.5f);
+    *w       = (int)fmaf(fr, 256.0f, 0.5f); /* fr >= 0: truncation == round-to-nearest of fr*256 */
     int a = i, b = i + 1;
     if (a < 0) a = 0;
     if (a > n - 1) a = n - 1;
