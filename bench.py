@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the volumetric radiance integrator on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one complete render job of the Julia-256^3 scene at 800x600: `spp` samples per pixel,
+pixel tiles dealt round-robin over the ranks, followed (N > 1) by one RCCL reduce of the HDR
+accumulators to rank 0.  spp = 1024 * N, so every GPU always integrates 800*600*1024 samples per
+step ("weak" scaling); at N = 1 this is BASELINE.json's configs[1] exactly.  Inputs are resident
+in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cuda-volpath_amd"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_sample(c):
+    """8*L_d + 2*L_b + 32*L_o + 16*L_e + 32 (accumulator read+write)."""
+    n = max(c["samples"], 1)
+    return (8.0 * c["density_lookups"] + 2.0 * c["bound_lookups"] + 32.0 * c["opacity_lookups"] +
+            16.0 * c["env_lookups"]) / n + 32.0
+
+
+def cpu_baseline(workload, seconds_hint=20.0):
+    """The oracle (CPU restatement, 'port') on this host's cores, on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    from volpath import scene as vscene
+    cfg = vscene.WORKLOADS[workload]
+    O.build()
+    grid = O.julia(cfg["n"])
+    osc = O.OracleScene(grid, vscene.gradient_sky(), vscene.DEFAULT_SUN_DIR, vscene.DEFAULT_SUN_POWER,
+                        brick=cfg["brick"], estimator=cfg["est"], rng_mode=O.RNG_PHILOX, seed=(0x9E3779B9, 0x85EBCA6B))
+    P = O.default_param(cfg["width"], cfg["height"])
+    cores = os.cpu_count() or 1
+    nframes, acc, tot, t0 = 0, None, 0, time.time()
+    budget = seconds_hint
+    while True:
+        acc, c = osc.render_frame(P, nframes, acc)
+        tot += c.samples
+        nframes += 1
+        if time.time() - t0 > budget or nframes >= 16:
+            break
+    dt = time.time() - t0
+    return {"value": tot / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"frames 0..{nframes - 1} of {cfg['width']}x{cfg['height']} ({tot} samples, {dt:.1f} s, "
+                      f"OpenMP over rows, Philox streams)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3ref", "c1"])
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
+    ap.add_argument("--rng", default="philox", choices=["philox", "samplerh"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import volpath as vp
+    from volpath import scene as vscene
+    vp.set_device(local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    vp.set_stream(stream.cuda_stream)
+
+    spp_step = args.spp * world
+    total_steps = args.warmup + args.steps
+    rng_mode = vp.RNG_PHILOX if args.rng == "philox" else vp.RNG_SAMPLERH
+    P, info = vscene.setup(args.workload, rng_mode=rng_mode, rank=rank, world=world,
+                           last_frame=spp_step * total_steps)
+    W, H = P.width, P.height
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        acc = torch.zeros(H, W, 4, device=dev, dtype=torch.float32)
+        image = torch.zeros(H, W, 4, device=dev, dtype=torch.float32) if rank == 0 else None
+
+        # work counters (untimed, counting kernel variant): per-sample lookups of THIS build
+        vp.enable_counters(True)
+        vp.read_counters(reset=True)
+        vp.render_frames(acc.data_ptr(), 0, 16 if args.workload != "c2" else 4, P)
+        counters = vp.read_counters(reset=True)
+        vp.enable_counters(False)
+        bytes_per_sample = algorithmic_bytes_per_sample(counters)
+
+        def step(i):
+            acc.zero_()
+            vp.render_frames(acc.data_ptr(), i * spp_step, spp_step, P)
+            if world > 1:
+                dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI
+            if rank == 0:
+                image.add_(acc)
+
+        for i in range(args.warmup):
+            step(i)
+        barrier()
+        vp.render_time_ms(reset=True)
+        t0 = time.perf_counter()
+        for i in range(args.warmup, total_steps):
+            step(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        kern_ms, launches = vp.render_time_ms(reset=True)
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        samples_total = float(W) * H * spp_step * args.steps           # all ranks together
+        samples_rank = float(W) * H * args.spp * args.steps             # this rank (its tiles)
+        value = samples_total / dt / 1e6
+        launch_ms = kern_ms / max(launches, 1)
+        bytes_per_launch = bytes_per_sample * samples_rank / max(launches, 1)
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            traffic = json.load(open(tp)).get(args.workload, {}).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "Msamples/sec (WxHxspp) + achieved HBM GB/s, Julia 256^3 @ 800x600",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": info["name"], "volume": f"{info['n']}^3 uchar Julia set", "image": f"{W}x{H}",
+                       "spp_per_step": spp_step, "samples_per_step": int(W * H * spp_step),
+                       "estimator": "global_majorant" if info["est"] == vp.EST_GLOBAL else "decomposition",
+                       "bound_brick": info["brick"], "rng": args.rng,
+                       "parallelism": f"pixel-tiles x{world}" + (" + RCCL reduce" if world > 1 else ""),
+                       "sky": "gradient placeholder + default sun (Hosek bake pending)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "vp::render_k", "launch_ms": launch_ms, "launches": launches,
+                         "algorithmic_bytes_per_sample": bytes_per_sample,
+                         "lookups_per_sample": {k: counters[k] / max(counters["samples"], 1) for k in
+                                                ("density_lookups", "bound_lookups", "opacity_lookups", "env_lookups", "scatters")}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

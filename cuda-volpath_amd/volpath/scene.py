@@ -1,0 +1,62 @@
+"""Scene set-up for the BASELINE configurations, mirroring the reference's main() (host.cpp:1284-1394).
+
+Builds the synthetic inputs of SURVEY.md section 8(d) (Julia-set volume, medium preset, camera,
+sun/sky) and hands them to the HIP library through the reference's entry points.
+"""
+import numpy as np
+
+from . import (EST_DECOMP, EST_GLOBAL, RNG_PHILOX, RNG_SAMPLERH, init_envmap, init_volume, julia_volume, make_param,
+               mat, precompute_opacity, set_camera, set_estimator, set_rng, set_shard, set_sun)
+
+# SURVEY.md section 4 anchors for setup_sunsky(0.5, 0.2) (host.cpp:1388-1390)
+DEFAULT_SUN_DIR = (-0.0, 0.951057, -0.309017)
+DEFAULT_SUN_POWER = (51797.34, 42480.11, 32578.49)
+PRESET1 = (2.29, 2.39, 1.97, 0.0030, 0.0034, 0.046)  # host.cpp:1296
+
+# BASELINE.json configs -> (volume edge, W, H, estimator, brick, chromatic)
+WORKLOADS = {
+    "c1": dict(n=128, width=400, height=300, est=EST_DECOMP, brick=1, chromatic=False,
+               name="julia128_400x300_decomp_refbounds"),
+    "c2": dict(n=256, width=800, height=600, est=EST_GLOBAL, brick=1, chromatic=False,
+               name="julia256_800x600_global_majorant"),
+    "c3": dict(n=256, width=800, height=600, est=EST_DECOMP, brick=8, chromatic=False,
+               name="julia256_800x600_decomp_brick8"),
+    "c3ref": dict(n=256, width=800, height=600, est=EST_DECOMP, brick=1, chromatic=False,
+                  name="julia256_800x600_decomp_refbounds"),
+}
+
+
+def gradient_sky(w=1024, h=512):
+    """Placeholder lat-long sky (smooth vertical gradient, flat ground) used until a baked Hosek map
+    is supplied; magnitudes follow the baked default sky (env[0] ~ (0.087, 0.115, 0.205))."""
+    env = np.zeros((h, w, 4), np.float32)
+    v = (np.arange(h, dtype=np.float32) + 0.5) / h
+    up = v < 0.5
+    t = np.clip(v / 0.5, 0, 1)[:, None]
+    sky = np.stack([0.087 + 0.25 * t, 0.115 + 0.27 * t, 0.205 + 0.25 * t], -1)[:, 0, :]
+    env[up, :, :3] = sky[up][:, None, :]
+    env[~up, :, :3] = np.float32(0.035)
+    env[..., 3] = 1.0
+    return env
+
+
+def setup(workload, rng_mode=RNG_PHILOX, key=(0x9E3779B9, 0x85EBCA6B), rank=0, world=1, env=None, opacity=True,
+          last_frame=0):
+    """Upload one BASELINE configuration; returns (Param, info)."""
+    cfg = WORKLOADS[workload]
+    grid = julia_volume(cfg["n"])
+    init_volume(grid, brick=cfg["brick"], linear=True)  # host.cpp:1342-1344
+    if env is None:
+        env = gradient_sky()
+    init_envmap(env)
+    set_sun(DEFAULT_SUN_DIR, DEFAULT_SUN_POWER)
+    set_camera()
+    set_estimator(cfg["est"])
+    set_rng(rng_mode, key)
+    set_shard(rank, world)
+    P = make_param(cfg["width"], cfg["height"])
+    if cfg["chromatic"]:
+        mat(P, *PRESET1)
+    if cfg["est"] == EST_DECOMP and opacity and last_frame > 10:
+        precompute_opacity(DEFAULT_SUN_DIR)  # host.cpp:336-343
+    return P, dict(cfg, occupancy=float(grid.mean() / 255.0))

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Regenerates the committed fixtures under tests/golden/.  Run in the build container:
+    python tests/golden/make_golden.py
+
+Sources, by authority:
+  ref_anchors.json   values recorded FROM THE REFERENCE (SURVEY.md section 4 / section 6 probes) and the
+                     published Random123 Philox known-answer vectors -- typed in, not computed here.
+  hosek_ref.npz      outputs of the reference's own Hosek sky sources (oracle/_ref/libhosek_ref.so,
+                     built by oracle/Makefile from /root/reference/src/sunsky/hosek where they lie).
+  oracle_*.npz       outputs of the CPU oracle (regression vectors for the GPU path; oracle-made).
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+import scenes  # noqa: E402
+
+
+def ref_anchors():
+    a = {
+        "source": "SURVEY.md section 4 (values captured from the reference's sampler.h / sky code) and section 6",
+        "hash": {"0": 0xc0a9496a, "1": 0x27922c9d, str(0x00030005): 0xb5ac5390},
+        "cudarng": {"3,5,7": [0.310083151, 0.486427426, 0.107821465, 0.729314804],
+                    "0,0,0": [0.484132648, 0.372826576, 0.202771664, 0.32959044]},
+        "default_sun_dir": [-0.0, 0.951057, -0.309017],
+        "default_sun_color_x0.02": [51797.34, 42480.11, 32578.49],
+        "default_env0": [0.087455, 0.115298, 0.204543],
+        "julia_occupancy": 0.0265,
+        "work_counters_julia256_800x600": {"density_lookups": 97.6, "bound_lookups": 51.3, "env_lookups": 1.0,
+                                           "zero_scatter_pixel_fraction": 0.88, "p90_scatters": 13.9,
+                                           "p99_scatters": 48.9},
+        "bound_radius": {"32": 1, "64": 2, "128": 4, "256": 7, "512": 13},
+        "philox4x32_10_random123_kat": [
+            {"ctr": [0, 0, 0, 0], "key": [0, 0], "out": [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]},
+            {"ctr": [0xffffffff] * 4, "key": [0xffffffff] * 2, "out": [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]},
+            {"ctr": [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], "key": [0xa4093822, 0x299f31d0],
+             "out": [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]}],
+    }
+    json.dump(a, open(os.path.join(HERE, "ref_anchors.json"), "w"), indent=1)
+
+
+def hosek_ref():
+    """Sky and solar radiance from the reference's Hosek-Wilkie implementation (alien-world init,
+    sky_tungsten.cpp:416-429: intensity 100, T=5777 K, turbidity 2, albedo 0.2)."""
+    path = os.path.join(ROOT, "oracle", "_ref", "libhosek_ref.so")
+    L = C.CDLL(path)
+    init = L._Z42arhosekskymodelstate_alienworld_alloc_initddddd
+    init.restype = C.c_void_p
+    init.argtypes = [C.c_double] * 5
+    rad = L._Z24arhosekskymodel_radianceP20ArHosekSkyModelStateddd
+    rad.restype = C.c_double
+    rad.argtypes = [C.c_void_p] + [C.c_double] * 3
+    srad = L._Z30arhosekskymodel_solar_radianceP20ArHosekSkyModelStateddd
+    srad.restype = C.c_double
+    srad.argtypes = [C.c_void_p] + [C.c_double] * 3
+    elevs = np.array([0.05, 0.3, 0.62831853, 1.0, 1.2566370614359172, 1.5], np.float64)  # incl. default (pi*0.4)
+    thetas = np.linspace(0.0, 1.55, 9)
+    gammas = np.linspace(0.0, 3.1, 9)
+    lambdas = np.array([360.0 + i * (830.0 - 360.0) / 9 for i in range(7)], np.float64)  # sky_tungsten.cpp:385-390
+    sky = np.zeros((len(elevs), len(thetas), len(gammas), len(lambdas)))
+    sun = np.zeros((len(elevs), len(lambdas)))
+    for a, el in enumerate(elevs):
+        st = init(float(el), 100.0, 5777.0, 2.0, 0.2)
+        for b, th in enumerate(thetas):
+            for c, ga in enumerate(gammas):
+                for d, lam in enumerate(lambdas):
+                    sky[a, b, c, d] = rad(st, float(th), float(ga), float(lam))
+        for d, lam in enumerate(lambdas):
+            sun[a, d] = srad(st, float(np.pi / 2 - el), 0.0, float(lam))
+    np.savez_compressed(os.path.join(HERE, "hosek_ref.npz"), elevations=elevs, thetas=thetas, gammas=gammas,
+                        lambdas=lambdas, sky_radiance=sky, solar_radiance=sun)
+
+
+def oracle_renders():
+    """Oracle accumulators for a tiny scene: Julia 32^3 @ 64x48, synthetic 64x32 sky, default sun/camera."""
+    grid = O.julia(32)
+    env = scenes.synthetic_env()
+    out = {"julia32": grid}
+    for est, name in ((O.EST_DECOMP, "decomp"), (O.EST_GLOBAL, "global")):
+        for rng, rname in ((O.RNG_SAMPLERH, "samplerh"), (O.RNG_PHILOX, "philox")):
+            sc = O.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, estimator=est,
+                               rng_mode=rng, seed=(123, 456))
+            sc.precompute_opacity()
+            P = O.default_param(64, 48)
+            acc = None
+            for f in range(14):
+                acc, _ = sc.render_frame(P, f, acc)
+            out[f"{name}_{rname}_f0_13"] = acc
+            if est == O.EST_DECOMP and rng == O.RNG_SAMPLERH:
+                out["opacity32"] = sc.opacity.astype(np.float32)
+                out["bounds32_r1"] = sc.bounds
+    # chromatic preset #1 with the brick table
+    g64 = O.julia(64)
+    sc = O.OracleScene(g64, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, brick=8)
+    P = O.mat(O.default_param(64, 48), *scenes.PRESET1)
+    acc = None
+    for f in range(4):
+        acc, _ = sc.render_frame(P, f, acc)
+    out["julia64_brick8_preset1_f0_3"] = acc
+    out["bounds64_brick8"] = sc.bounds
+    np.savez_compressed(os.path.join(HERE, "oracle_renders.npz"), **out)
+
+
+if __name__ == "__main__":
+    O.build()
+    ref_anchors()
+    hosek_ref()
+    oracle_renders()
+    print("golden fixtures written to", HERE)

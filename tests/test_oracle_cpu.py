@@ -1,0 +1,181 @@
+"""CPU suite, part 1: the oracle against reference-derived anchors and committed golden vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ANCH = json.load(open(os.path.join(HERE, "golden", "ref_anchors.json")))
+GOLD = np.load(os.path.join(HERE, "golden", "oracle_renders.npz"))
+
+
+def test_hash_and_cudarng_match_reference_anchors(oracle):
+    for k, v in ANCH["hash"].items():
+        assert oracle.lib().vpo_hash(int(k)) == v
+    for k, vals in ANCH["cudarng"].items():
+        x, y, f = (int(t) for t in k.split(","))
+        got = oracle.rng_stream(oracle.RNG_SAMPLERH, x, y, f, len(vals))
+        assert np.array_equal(got, np.array(vals, np.float32))
+
+
+def test_philox_random123_kat(oracle):
+    for kat in ANCH["philox4x32_10_random123_kat"]:
+        assert oracle.philox(kat["ctr"], kat["key"]) == kat["out"]
+    # draw n of stream (x,y,frame) = word n%4 of block (x,y,frame,n//4)
+    s = oracle.rng_stream(oracle.RNG_PHILOX, 3, 5, 7, 8, key=(11, 22))
+    for n in range(8):
+        w = oracle.philox([3, 5, 7, n // 4], [11, 22])[n % 4]
+        assert s[n] == np.float32(np.uint32(0x3f800000 | (w >> 9)).view(np.float32) - np.float32(1.0))
+
+
+def test_rng_float_range(oracle):
+    for mode in (0, 1):
+        s = oracle.rng_stream(mode, 17, 4, 99, 4096)
+        assert s.min() >= 0.0 and s.max() < 1.0
+
+
+def test_julia_voxeliser(oracle):
+    assert np.array_equal(oracle.julia(32), GOLD["julia32"])
+    occ = oracle.julia(128).mean() / 255.0
+    assert abs(occ - ANCH["julia_occupancy"]) < 2e-4
+    g = oracle.julia(32)
+    assert set(np.unique(g)) <= {0, 255}
+
+
+def test_bound_radius(oracle):
+    for n, r in ANCH["bound_radius"].items():
+        assert oracle.bound_radius(int(n)) == r
+
+
+@pytest.mark.parametrize("brick", [1, 4])
+def test_bounds_against_brute_force(oracle, brick):
+    rng = np.random.default_rng(2)
+    g = (rng.random((10, 12, 16)) * 255).astype(np.uint8)
+    g[rng.random(g.shape) < 0.5] = 0
+    r = 2
+    got = oracle.bounds(g, r, brick)
+    nz, ny, nx = g.shape
+    for bk in range(got.shape[0]):
+        for bj in range(got.shape[1]):
+            for bi in range(got.shape[2]):
+                k0, k1 = max(bk * brick - r, 0), min(bk * brick + brick - 1 + r, nz - 1)
+                j0, j1 = max(bj * brick - r, 0), min(bj * brick + brick - 1 + r, ny - 1)
+                i0, i1 = max(bi * brick - r, 0), min(bi * brick + brick - 1 + r, nx - 1)
+                w = g[k0:k1 + 1, j0:j1 + 1, i0:i1 + 1]
+                assert got[bk, bj, bi, 0] == w.max() and got[bk, bj, bi, 1] == w.min()
+    gf = g.astype(np.float32) / 255
+    assert np.array_equal(oracle.bounds(gf, r, brick)[..., 0], got[..., 0].astype(np.float32) / 255)
+
+
+def test_golden_renders_regression(oracle):
+    grid = GOLD["julia32"]
+    env = scenes.synthetic_env()
+    for est, name in ((oracle.EST_DECOMP, "decomp"), (oracle.EST_GLOBAL, "global")):
+        for rng, rname in ((oracle.RNG_SAMPLERH, "samplerh"), (oracle.RNG_PHILOX, "philox")):
+            sc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, estimator=est,
+                                    rng_mode=rng, seed=(123, 456))
+            sc.precompute_opacity()
+            if est == oracle.EST_DECOMP and rng == oracle.RNG_SAMPLERH:
+                assert np.array_equal(sc.opacity, GOLD["opacity32"])
+                assert np.array_equal(sc.bounds, GOLD["bounds32_r1"])
+            P = oracle.default_param(64, 48)
+            acc = None
+            for f in range(14):
+                acc, _ = sc.render_frame(P, f, acc)
+            assert np.array_equal(acc, GOLD[f"{name}_{rname}_f0_13"]), (name, rname)
+
+
+def test_thread_count_invariance(oracle):
+    grid = GOLD["julia32"]
+    sc = oracle.OracleScene(grid, scenes.synthetic_env(), scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+    P = oracle.default_param(64, 48)
+    a, _ = sc.render_frame(P, 3, threads=1)
+    b, _ = sc.render_frame(P, 3, threads=4)
+    assert np.array_equal(a, b)
+
+
+def test_work_counters_match_reference_probe(oracle):
+    """per-sample work of the reference's live kernel on Julia 256^3 @ 800x600."""
+    ref = ANCH["work_counters_julia256_800x600"]
+    g = oracle.julia(256)
+    sc = oracle.OracleScene(g, scenes.synthetic_env(), scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+    P = oracle.default_param(800, 600)
+    acc, c = sc.render_frame(P, 0)
+    n = c.samples
+    assert abs(c.density_lookups / n / ref["density_lookups"] - 1) < 0.03
+    assert abs(c.bound_lookups / n / ref["bound_lookups"] - 1) < 0.01
+    assert c.env_lookups == n
+    assert abs((acc[..., 3] == 0).mean() - ref["zero_scatter_pixel_fraction"]) < 0.01
+
+
+def test_white_furnace(oracle):
+    """albedo 1, constant environment, no sun: every sample returns the environment constant."""
+    g = oracle.julia(32)
+    env = np.zeros((8, 16, 4), np.float32)
+    env[..., :3] = 0.5
+    for est in (oracle.EST_DECOMP, oracle.EST_GLOBAL):
+        sc = oracle.OracleScene(g, env, scenes.DEFAULT_SUN_DIR, (0.0, 0.0, 0.0), estimator=est)
+        P = oracle.default_param(48, 36)
+        acc = None
+        for f in range(4):
+            acc, _ = sc.render_frame(P, f, acc)
+        rgb = acc[..., :3] / 4
+        # the only loss is the max_depth=800 cut (kernel.cu:34) and float drift of the unit weights
+        assert np.abs(rgb - 0.5).max() < 2e-3
+
+
+def test_majorant_invariance(oracle):
+    """global-majorant and decomposition tracking estimate the same integral (frames <= 10: no opacity table)."""
+    g = oracle.julia(32)
+    env = scenes.synthetic_env()
+    imgs = []
+    for est in (oracle.EST_DECOMP, oracle.EST_GLOBAL):
+        sc = oracle.OracleScene(g, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, estimator=est,
+                                rng_mode=oracle.RNG_PHILOX, seed=(5, est))
+        P = oracle.default_param(32, 24, density=40.0)
+        acc = None
+        for f in range(10):
+            acc, _ = sc.render_frame(P, f, acc)
+        imgs.append(acc[..., :3].mean(axis=(0, 1)) / 10)
+    assert np.allclose(imgs[0], imgs[1], rtol=0.08)
+
+
+def test_math_accuracy(oracle):
+    rng = np.random.default_rng(1)
+    u = rng.random(200000).astype(np.float32)
+    u = u[u > 0]
+
+    def ulps(a, exact):
+        sp = np.abs(np.spacing(exact.astype(np.float32))).astype(np.float64)
+        return np.max(np.abs(a.astype(np.float64) - exact) / sp)
+
+    assert ulps(oracle.math_array(0, u), np.log(u.astype(np.float64))) < 1.0
+    xe = (-80 * u).astype(np.float32)
+    assert ulps(oracle.math_array(1, xe), np.exp(xe.astype(np.float64))) < 1.5
+    xa = (u * 6.2831855).astype(np.float32)
+    assert np.abs(oracle.math_array(2, xa) - np.sin(xa.astype(np.float64))).max() < 2e-7
+    assert np.abs(oracle.math_array(3, xa) - np.cos(xa.astype(np.float64))).max() < 2e-7
+    xc = (u * 2 - 1).astype(np.float32)
+    assert ulps(oracle.math_array(4, xc), np.arccos(xc.astype(np.float64))) < 2.0
+    xt = np.tan((u - 0.5) * 3.1).astype(np.float32)
+    assert ulps(oracle.math_array(5, xt), np.arctan(xt.astype(np.float64))) < 4.0
+    assert oracle.math_array(0, np.zeros(1, np.float32))[0] == -np.inf
+    assert oracle.math_array(5, np.array([np.inf, -np.inf, np.nan], np.float32)).tolist() == \
+        [np.float32(np.pi / 2), -np.float32(np.pi / 2), 0.0]
+
+
+def test_scale_gamma_and_mat(oracle):
+    import ctypes as C
+    src = np.random.default_rng(0).random((5, 4), dtype=np.float32)
+    dst = np.empty_like(src)
+    oracle.lib().vpo_scale(dst.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), 5, 0.25)
+    assert np.array_equal(dst, src * np.float32(0.25))
+    oracle.lib().vpo_gamma_correct(dst.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), 5, 0.5, 2.2)
+    assert np.allclose(dst[:, :3], (src[:, :3] * 0.5) ** (1 / 2.2), rtol=2e-6) and np.all(dst[:, 3] == 1)
+    P = oracle.mat(oracle.default_param(4, 4), *scenes.PRESET1)  # host.cpp:1296
+    st = np.array([2.29 + 0.0030, 2.39 + 0.0034, 1.97 + 0.046])
+    assert np.allclose(list(P.sigma_t), st / st.max(), rtol=1e-6)
+    assert np.allclose(list(P.albedo), np.array([2.29, 2.39, 1.97]) / st, rtol=1e-6)
