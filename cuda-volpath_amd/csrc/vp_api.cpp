@@ -52,6 +52,8 @@ struct State
     unsigned*   d_queue       = nullptr;
     unsigned long long* d_counters = nullptr;
     bool        count       = false;
+    unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS;
+    unsigned    blocks_per_cu = 8;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> event_pool;
     float       inv_model[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
@@ -103,6 +105,10 @@ int ensure_device()
     HIPCHK(hipMemset(G.d_counters, 0, 8 * sizeof(unsigned long long)));
     G.S.sun_cos = 94.0f / sqrtf(94.0f * 94.0f + 0.45f * 0.45f);                    // kernel.cu:1263
     G.S.cam_z   = (float)(-1.0f / tan((double)54.43f * 0.00872664626));             // kernel.cu:1981-1985
+    // tuning knobs (performance only; results never depend on them)
+    if (const char* e = getenv("VP_WAIT_LANES")) G.wait_lanes = (unsigned)atoi(e);
+    if (const char* e = getenv("VP_WAIT_ITERS")) G.wait_iters = (unsigned)atoi(e);
+    if (const char* e = getenv("VP_BLOCKS_PER_CU")) G.blocks_per_cu = (unsigned)atoi(e);
     G.dev_ready = true;
     return VP_OK;
 }
@@ -257,6 +263,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p)
     L.queue = G.d_queue;
     L.counters = G.count ? G.d_counters : nullptr;
     L.key0 = G.key0; L.key1 = G.key1;
+    L.wait_lanes = G.wait_lanes; L.wait_iters = G.wait_iters;
     if (L.ntiles_owned == 0) return VP_OK;
     const size_t per_frame = (size_t)L.ntiles_owned * 64;
     size_t max_f = kMaxStageBytes / (per_frame * sizeof(float4));
@@ -289,7 +296,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p)
         HIPCHK(hipMemsetAsync(G.d_queue, 0, sizeof(unsigned), G.stream));
         unsigned waves  = (L.total_items + 63) / 64;
         unsigned blocks = (waves + (VP_BLOCK / 64) - 1) / (VP_BLOCK / 64);
-        unsigned cap    = (unsigned)G.num_cu * 8u;
+        unsigned cap    = (unsigned)G.num_cu * G.blocks_per_cu;
         if (blocks > cap) blocks = cap;
         hipEvent_t e0 = get_event(), e1 = get_event();
         HIPCHK(hipEventRecord(e0, G.stream));

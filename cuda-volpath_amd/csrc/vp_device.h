@@ -142,18 +142,19 @@ __device__ __forceinline__ f3 to_local(const SceneDev& S, f3 pos)
     return f3{(pos.x - S.bmin[0]) * S.linv[0], (pos.y - S.bmin[1]) * S.linv[1], (pos.z - S.bmin[2]) * S.linv[2]};
 }
 
-// texel-centre split of one axis: cell index (clamped) and 8-bit weight in 0..256
-__device__ __forceinline__ void axis_linear(float pn, int n, int& i, int& w)
+// texel-centre split of one axis: cell index (clamped) and the 8-bit filter weight as a float w/256
+// (an exact multiple of 2^-8 in [0,1])
+__device__ __forceinline__ void axis_linear(float pn, int n, int& i, float& fw)
 {
     float xb = fma_(pn, (float)n, -0.5f);  // the unit's own scaling: one rounding
     float fl = __builtin_floorf(xb);
     float fr = xb - fl;
     i        = (int)fl;
-    w        = (int)fma_(fr, 256.0f, 0.5f);  // fr >= 0: truncation == round-to-nearest of fr*256
+    fw       = __builtin_floorf(fma_(fr, 256.0f, 0.5f)) * (1.0f / 256.0f);  // round-to-nearest of fr*256, /256
     // the packed cell of voxel i already holds the clamped (i, i+1) pair; i < 0 degenerates to texel 0
-    w = i < 0 ? 0 : w;
-    i = i < 0 ? 0 : i;
-    i = i > n - 1 ? n - 1 : i;
+    fw = i < 0 ? 0.0f : fw;
+    i  = i < 0 ? 0 : i;
+    i  = i > n - 1 ? n - 1 : i;
 }
 __device__ __forceinline__ int axis_point(float pn, int n)
 {
@@ -165,54 +166,59 @@ __device__ __forceinline__ int axis_point(float pn, int n)
 
 __device__ __forceinline__ float lerpf(float a, float b, float w) { return a * (1.0f - w) + b * w; }
 
-// filter the 8 bytes of a packed cell; exact integer arithmetic, one multiply to normalise
-__device__ __forceinline__ float filter_cell_u8(uint2 c, unsigned wx, unsigned wy, unsigned wz)
+// Filter the 8 bytes of a packed cell.  Defined (oracle: sample_volume) as the EXACT integer sum
+//   v = sum_t t * wx' * wy' * wz'   (weights in 0..256, v <= 255 * 2^24), result = float(v) * fl(1/(255*2^24)).
+// Evaluated here in binary32 without any rounding before the last step: with weights w/256 every
+// x- and y-stage value is an integer multiple of 2^-16 below 2^8 (<= 24 significant bits, exact), and
+// the z-stage is ONE fma, so its result is the correctly rounded v / 2^24 = float(v) / 2^24.
+__device__ __forceinline__ float filter_cell_u8(uint2 c, float fx, float fy, float fz)
 {
-    unsigned t000 = c.x & 0xffu, t100 = (c.x >> 8) & 0xffu, t010 = (c.x >> 16) & 0xffu, t110 = c.x >> 24;
-    unsigned t001 = c.y & 0xffu, t101 = (c.y >> 8) & 0xffu, t011 = (c.y >> 16) & 0xffu, t111 = c.y >> 24;
-    // every operand is < 2^24, every result < 2^32: full-rate v_mul/mad_u32_u24
-    unsigned ix   = 256u - wx, iy = 256u - wy, iz = 256u - wz;
-    unsigned x00  = __umul24(t000, ix) + __umul24(t100, wx);
-    unsigned x10  = __umul24(t010, ix) + __umul24(t110, wx);
-    unsigned x01  = __umul24(t001, ix) + __umul24(t101, wx);
-    unsigned x11  = __umul24(t011, ix) + __umul24(t111, wx);
-    unsigned y0   = __umul24(x00, iy) + __umul24(x10, wy);
-    unsigned y1   = __umul24(x01, iy) + __umul24(x11, wy);
-    unsigned v    = __umul24(y0, iz) + __umul24(y1, wz);
-    return (float)v * VP_U8_TRI_SCALE;
+    // (float)(byte k of a dword) selects v_cvt_f32_ubyte<k>
+    float t000 = (float)(c.x & 0xffu), t100 = (float)((c.x >> 8) & 0xffu);
+    float t010 = (float)((c.x >> 16) & 0xffu), t110 = (float)(c.x >> 24);
+    float t001 = (float)(c.y & 0xffu), t101 = (float)((c.y >> 8) & 0xffu);
+    float t011 = (float)((c.y >> 16) & 0xffu), t111 = (float)(c.y >> 24);
+    float x00  = fma_(t100 - t000, fx, t000);
+    float x10  = fma_(t110 - t010, fx, t010);
+    float x01  = fma_(t101 - t001, fx, t001);
+    float x11  = fma_(t111 - t011, fx, t011);
+    float y0   = fma_(x10 - x00, fy, x00);
+    float y1   = fma_(x11 - x01, fy, x01);
+    float v    = fma_(y1 - y0, fz, y0);  // = float(v_int) * 2^-24, one rounding
+    return v * (VP_U8_TRI_SCALE * 16777216.0f);
 }
 
 // normalised density in [0,1] at a world position: tex3D<float>(density_tex) of kernel.cu:692
 template <bool QUANT>
 __device__ __forceinline__ float sample_density01(const SceneDev& S, f3 pos)
 {
-    f3  p = to_local(S, pos);
-    int i, j, k, wx, wy, wz;
+    f3    p = to_local(S, pos);
+    int   i, j, k;
+    float fx, fy, fz;
     if (S.linear)
     {
-        axis_linear(p.x, S.nx, i, wx);
-        axis_linear(p.y, S.ny, j, wy);
-        axis_linear(p.z, S.nz, k, wz);
+        axis_linear(p.x, S.nx, i, fx);
+        axis_linear(p.y, S.ny, j, fy);
+        axis_linear(p.z, S.nz, k, fz);
     }
     else
     {
         i = axis_point(p.x, S.nx);
         j = axis_point(p.y, S.ny);
         k = axis_point(p.z, S.nz);
-        wx = wy = wz = 0;
+        fx = fy = fz = 0.0f;
     }
     // dims <= 4096 (checked by init_cuda): 24-bit operands, 32-bit result
     size_t idx = (size_t)((unsigned)i + __umul24((unsigned)S.nx, (unsigned)j + __umul24((unsigned)S.ny, (unsigned)k)));
     if (QUANT)
     {
         uint2 c = S.cells_u8[idx];
-        return filter_cell_u8(c, (unsigned)wx, (unsigned)wy, (unsigned)wz);
+        return filter_cell_u8(c, fx, fy, fz);
     }
     else
     {
         const float4* q  = reinterpret_cast<const float4*>(S.cells_f32) + idx * 2;
         float4        lo = q[0], hi = q[1];
-        float fx = (float)wx * (1.0f / 256.0f), fy = (float)wy * (1.0f / 256.0f), fz = (float)wz * (1.0f / 256.0f);
         float x00 = lerpf(lo.x, lo.y, fx);
         float x10 = lerpf(lo.z, lo.w, fx);
         float x01 = lerpf(hi.x, hi.y, fx);

@@ -12,7 +12,7 @@
 #define VP_WAIT_LANES 16
 #endif
 #ifndef VP_WAIT_ITERS
-#define VP_WAIT_ITERS 32
+#define VP_WAIT_ITERS 16
 #endif
 
 namespace vp
@@ -34,6 +34,7 @@ struct LaunchDev
     unsigned* queue;       // sample queue head (zeroed before the launch)
     unsigned long long* counters;  // 6 words (samples, density, bound, opacity, env, scatters) or null
     unsigned key0, key1;   // Philox key
+    unsigned wait_lanes, wait_iters;  // inner-loop exit policy (VP_WAIT_LANES / VP_WAIT_ITERS)
 };
 
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int blocks, hipStream_t st);

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(VP_BLOCK) void render_k(SceneDev S, LaunchDev L)
             unsigned long long am = __ballot(active);
             unsigned long long wm = __ballot(!active && !(st == ST_DONE && exhausted));
             unsigned nwait = (unsigned)__popcll(wm);
-            if (am == 0ull || nwait >= (unsigned)VP_WAIT_LANES || (nwait > 0u && iter >= VP_WAIT_ITERS)) break;
+            if (am == 0ull || nwait >= L.wait_lanes || (nwait > 0u && iter >= (int)L.wait_iters)) break;
             if (!active) continue;
 
             if (EST == EST_DECOMP && st == ST_SETUP)

@@ -1,0 +1,6 @@
+#!/bin/bash
+# sweep the inner-loop exit policy; usage: sweep.sh EST BRICK RNG FRAMES
+for wl in 4 8 16 24 32; do for wi in 8 32 128; do
+  echo -n "wait_lanes=$wl wait_iters=$wi: "
+  VP_WAIT_LANES=$wl VP_WAIT_ITERS=$wi python3 scripts/prof_case.py "$@" | tail -1
+done; done
