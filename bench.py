@@ -29,6 +29,18 @@ def algorithmic_bytes_per_sample(c):
             16.0 * c["env_lookups"]) / n + 32.0
 
 
+def effective_cores():
+    """CPUs this process may really use: affinity mask and cgroup quota, not the host's core count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(workload, seconds_hint=20.0):
     """The oracle (CPU restatement, 'port') on this host's cores, on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -41,11 +53,11 @@ def cpu_baseline(workload, seconds_hint=20.0):
     osc = O.OracleScene(grid, vscene.gradient_sky(), vscene.DEFAULT_SUN_DIR, vscene.DEFAULT_SUN_POWER,
                         brick=cfg["brick"], estimator=cfg["est"], rng_mode=O.RNG_PHILOX, seed=(0x9E3779B9, 0x85EBCA6B))
     P = O.default_param(cfg["width"], cfg["height"])
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     nframes, acc, tot, t0 = 0, None, 0, time.time()
     budget = seconds_hint
     while True:
-        acc, c = osc.render_frame(P, nframes, acc)
+        acc, c = osc.render_frame(P, nframes, acc, threads=cores)
         tot += c.samples
         nframes += 1
         if time.time() - t0 > budget or nframes >= 16:
