@@ -40,16 +40,21 @@ def gradient_sky(w=1024, h=512):
     return env
 
 
-def setup(workload, rng_mode=RNG_PHILOX, key=(0x9E3779B9, 0x85EBCA6B), rank=0, world=1, env=None, opacity=True,
+def default_sunsky():
+    """setup_sunsky(0.5, 0.2) + update_sunsky (host.cpp:1388-1390, :276-333) through the C++ host library."""
+    from . import host
+    return host.bake_sunsky(0.5, 0.2, 1024, 512)
+
+
+def setup(workload, rng_mode=RNG_PHILOX, key=(0x9E3779B9, 0x85EBCA6B), rank=0, world=1, sunsky=None, opacity=True,
           last_frame=0):
     """Upload one BASELINE configuration; returns (Param, info)."""
     cfg = WORKLOADS[workload]
     grid = julia_volume(cfg["n"])
     init_volume(grid, brick=cfg["brick"], linear=True)  # host.cpp:1342-1344
-    if env is None:
-        env = gradient_sky()
+    env, sun_dir, sun_power = sunsky if sunsky is not None else default_sunsky()
     init_envmap(env)
-    set_sun(DEFAULT_SUN_DIR, DEFAULT_SUN_POWER)
+    set_sun(sun_dir, sun_power)
     set_camera()
     set_estimator(cfg["est"])
     set_rng(rng_mode, key)
@@ -58,5 +63,5 @@ def setup(workload, rng_mode=RNG_PHILOX, key=(0x9E3779B9, 0x85EBCA6B), rank=0, w
     if cfg["chromatic"]:
         mat(P, *PRESET1)
     if cfg["est"] == EST_DECOMP and opacity and last_frame > 10:
-        precompute_opacity(DEFAULT_SUN_DIR)  # host.cpp:336-343
-    return P, dict(cfg, occupancy=float(grid.mean() / 255.0))
+        precompute_opacity(sun_dir)  # host.cpp:336-343
+    return P, dict(cfg, occupancy=float(grid.mean() / 255.0), sunsky=(env, sun_dir, sun_power))

@@ -1,0 +1,152 @@
+"""CPU suite, part 4: the C++ host side (sun/sky, image writers, volume ingest, camera, presets)."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ANCH = json.load(open(os.path.join(HERE, "golden", "ref_anchors.json")))
+
+
+@pytest.fixture(scope="module")
+def host():
+    from volpath import host as h
+    h.lib()
+    return h
+
+
+def test_hosek_restatement_matches_reference_outputs(host):
+    """tests/golden/hosek_ref.npz was produced by the reference's own ArHosekSkyModel.cpp (oracle/_ref)."""
+    g = np.load(os.path.join(HERE, "golden", "hosek_ref.npz"))
+    worst = 0.0
+    for a, el in enumerate(g["elevations"]):
+        for b, th in enumerate(g["thetas"]):
+            for c, ga in enumerate(g["gammas"]):
+                for d, lam in enumerate(g["lambdas"]):
+                    sky, _ = host.hosek(float(el), float(th), float(ga), float(lam))
+                    ref = g["sky_radiance"][a, b, c, d]
+                    worst = max(worst, abs(sky - ref) / max(abs(ref), 1e-300))
+        for d, lam in enumerate(g["lambdas"]):
+            _, sun = host.hosek(float(el), float(np.pi / 2 - el), 0.0, float(lam))
+            ref = g["solar_radiance"][a, d]
+            worst = max(worst, abs(sun - ref) / abs(ref))
+    assert worst < 1e-12, worst
+    with pytest.raises(ValueError):
+        host.hosek(0.5, 0.3, 0.3, 500.0, turbidity=3.0)
+
+
+def test_default_sunsky_matches_reference_anchors(host):
+    """values the reference produces for setup_sunsky(0.5, 0.2)."""
+    env, sun_dir, sun_power = host.bake_sunsky(0.5, 0.2)
+    assert np.allclose(sun_dir, ANCH["default_sun_dir"], atol=2e-6)
+    assert np.allclose(sun_power, ANCH["default_sun_color_x0.02"], rtol=2e-6)
+    assert np.allclose(env[0, 0, :3], ANCH["default_env0"], rtol=2e-5)
+    assert env.shape == (512, 1024, 4) and np.all(env[:256, :, 3] == np.float32(0.02)) and np.all(env[256:, :, 3] == 1.0)
+    # lower hemisphere: 0.01 * sun_dir.y * sun_power * pi (0.45/94)^2 (host.cpp:317-320)
+    disc = np.float32(np.float64(np.float32(np.pi)) * (0.45 / np.float32(94.0) * 0.45 / np.float32(94.0)))
+    ground = (np.float32(0.01) * sun_dir[1]) * sun_power * disc
+    assert np.allclose(env[300, 17, :3], ground, rtol=1e-6)
+    assert np.isfinite(env).all() and (env[:256, :, :3] > 0).all()
+
+
+def test_sky_color_sun_disc_switch(host):
+    theta, phi = 0.2 * 0.5 * np.float32(np.pi), 0.5 * 2 * np.float32(np.pi)
+    rgb, d = host.sun_color(theta, phi)
+    assert np.allclose(host.sky_color(theta, phi, d, cel=True), rgb)
+    assert not np.allclose(host.sky_color(theta, phi, d, cel=False), rgb)
+
+
+def test_camera_matrix_matches_h4(host):
+    import volpath
+    m = host.camera_matrix()
+    assert np.allclose(m, volpath.DEFAULT_CAMERA, atol=2e-6)
+    # orthonormal rotation part
+    R = m.reshape(3, 4)[:, :3]
+    assert np.allclose(R.T @ R, np.eye(3), atol=1e-5)
+
+
+def test_material_presets(host):
+    X = [(2.29, 2.39, 1.97, 0.0030, 0.0034, 0.046), (1.0, 1.0, 1.0, 0.0, 0.0, 0.0)]
+    for idx, (a, b, c, r, g, bl) in zip((0, 12), X):
+        st, al = host.material_preset(idx)
+        t = np.array([a + r, b + g, c + bl])
+        assert np.allclose(st, t / t.max(), rtol=1e-6) and np.allclose(al, np.array([a, b, c]) / t, rtol=1e-6)
+    with pytest.raises(IndexError):
+        host.material_preset(13)
+
+
+def test_ppm_writer_bytes(host, tmp_path):
+    img = np.zeros((2, 3, 4), np.float32)
+    img[0, 0, :3] = (0.0, 0.5, 1.0)
+    img[0, 1, :3] = (2.0, 0.999, 0.25)
+    img[1, 2, :3] = (1 / 255 + 1e-4, 0.1, 0.9)
+    p = str(tmp_path / "a.ppm")
+    host.write_image(img, p)
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"P6\n3 2\n255\n")
+    px = np.frombuffer(raw[len(b"P6\n3 2\n255\n"):], np.uint8).reshape(2, 3, 3)
+    # rows are written bottom-up; channel = trunc(min(1, v) * 255)  (image.cpp:31-39)
+    assert px[1, 0].tolist() == [0, 127, 255] and px[1, 1].tolist() == [255, 254, 63]
+    assert px[0, 2].tolist() == [1, 25, 229]
+
+
+def test_hdr_writer_roundtrip(host, tmp_path):
+    rng = np.random.default_rng(3)
+    img = np.zeros((5, 130, 4), np.float32)  # > 127 wide: two literal runs per plane
+    img[..., :3] = rng.random((5, 130, 3), dtype=np.float32) * 50
+    img[0, 0, :3] = 0
+    p = str(tmp_path / "a.hdr")
+    host.write_image(img, p, hdr=True)
+    raw = open(p, "rb").read()
+    head = b"#?RADIANCE\n# Made with custom writer\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y 5 +X 130\n"
+    assert raw.startswith(head)
+    body = raw[len(head):]
+    off = 0
+    for row in range(4, -1, -1):
+        assert body[off:off + 4] == bytes([2, 2, 0, 130])
+        off += 4
+        planes = []
+        for k in range(4):
+            vals = []
+            while len(vals) < 130:
+                run = body[off]
+                assert 0 < run <= 127
+                vals += list(body[off + 1:off + 1 + run])
+                off += 1 + run
+            planes.append(vals)
+        rgbe = np.array(planes, np.float64).T
+        dec = rgbe[:, :3] * np.where(rgbe[:, 3:] > 0, 2.0 ** (rgbe[:, 3:] - 136), 0)
+        assert np.all(np.abs(dec - img[row, :, :3]) <= img[row, :, :3].max(axis=1, keepdims=True) / 128 + 1e-6)
+    assert off == len(body)
+
+
+def test_image_ops(host):
+    rng = np.random.default_rng(1)
+    img = rng.random((4, 5, 4), dtype=np.float32) * 2
+    assert np.array_equal(host.image_op(img, "scale", 0.5), img * np.float32(0.5))
+    assert np.array_equal(host.image_op(img, "flip"), img[::-1])
+    gm = host.image_op(img, "gamma", 2.2)
+    assert np.allclose(gm[..., :3], np.clip(img[..., :3], 0, 1) ** (1 / 2.2), rtol=1e-5) and np.array_equal(gm[..., 3], img[..., 3])
+    rh = host.image_op(img, "reinhard")
+    assert ((rh[..., :3] >= 0) & (rh[..., :3] < 1)).all()
+
+
+def test_dense_dump_roundtrip_and_quantisers(host, tmp_path):
+    rng = np.random.default_rng(2)
+    vol = (rng.random((3, 4, 5), dtype=np.float32) * 1.4 - 0.2).astype(np.float32)
+    p = str(tmp_path / "v.bin")
+    assert host.dump_dense(p, vol)
+    raw = open(p, "rb").read()
+    assert struct.unpack("<iii", raw[:12]) == (5, 4, 3) and len(raw) == 12 + 60 * 4   # load_vdb.cpp:52-69
+    f = host.load_binary(p, quantized=False)
+    assert f.shape == (3, 4, 5) and np.array_equal(f, vol)
+    q = host.load_binary(p, quantized=True)
+    assert np.array_equal(q, (np.clip(vol, 0, 1) * np.float32(255)).astype(np.uint8))             # host.cpp:955
+    qm = host.quantize(vol, max_value=float(vol.max()))
+    assert np.array_equal(qm, (np.maximum(vol, 0) / np.float32(vol.max()) * np.float32(255)).astype(np.uint8))  # host.cpp:1009
+    assert host.load_binary(str(tmp_path / "missing.bin")) is None
+    open(str(tmp_path / "bad.bin"), "wb").write(struct.pack("<iii", -1, 2, 2))
+    assert host.load_binary(str(tmp_path / "bad.bin")) is None
+    assert host.load_vdb(str(tmp_path / "missing.vdb")) is None
