@@ -203,3 +203,27 @@ def test_full_size_properties(vp):
     assert np.array_equal(tot, ia)
     a.free()
     b.free()
+
+
+def test_cli_render_matches_oracle_ppm(vp, oracle, tmp_path):
+    """volpath_render (C++ host: Hosek sky bake, camera, reference entry points, gamma, PPM writer) end to end."""
+    import ctypes as C
+    import os
+    import subprocess
+    from volpath import host
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cuda-volpath_amd", "volpath_render")
+    out = str(tmp_path / "cli.ppm")
+    r = subprocess.run([exe, "--julia", "32", "--size", "64", "48", "--spp", "4", "--out", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env, sun_dir, sun_power = host.bake_sunsky(0.5, 0.2)
+    osc = oracle.OracleScene(oracle.julia(32), env, sun_dir, sun_power, inv_view=host.camera_matrix())
+    acc, _ = _oracle_frames(osc, oracle.default_param(64, 48), range(4))
+    disp = np.empty_like(acc)
+    oracle.lib().vpo_gamma_correct(disp.ctypes.data_as(C.c_void_p), acc.ctypes.data_as(C.c_void_p), 64 * 48, 0.25, 2.2)
+    expect = (np.minimum(disp[::-1, :, :3], 1.0) * np.float32(255)).astype(np.uint8)
+    raw = open(out, "rb").read()
+    head = b"P6\n64 48\n255\n"
+    assert raw.startswith(head)
+    got = np.frombuffer(raw[len(head):], np.uint8).reshape(48, 64, 3)
+    assert np.array_equal(got, expect)
