@@ -54,6 +54,7 @@ struct State
     bool        count       = false;
     unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS;
     unsigned    blocks_per_cu = 8;
+    bool        use_lds_bounds = true;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> event_pool;
     float       inv_model[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
@@ -109,6 +110,7 @@ int ensure_device()
     if (const char* e = getenv("VP_WAIT_LANES")) G.wait_lanes = (unsigned)atoi(e);
     if (const char* e = getenv("VP_WAIT_ITERS")) G.wait_iters = (unsigned)atoi(e);
     if (const char* e = getenv("VP_BLOCKS_PER_CU")) G.blocks_per_cu = (unsigned)atoi(e);
+    if (const char* e = getenv("VP_NO_LDS_BOUNDS")) G.use_lds_bounds = atoi(e) == 0;
     G.dev_ready = true;
     return VP_OK;
 }
@@ -177,7 +179,8 @@ int do_init_volume(const void* h_volume, vp_extent ext, bool quantized, const vp
     {
         std::vector<uint8_t> b(nb * 2);
         build_bounds_u8((const uint8_t*)h_volume, nx, ny, nz, G.radius, G.brick, b.data());
-        HIPCHK(hipMalloc(&G.d_bounds, nb * 2));
+        HIPCHK(hipMalloc(&G.d_bounds, nb * 2 + 16));  // padded: the LDS stage copies whole 16-byte words
+        HIPCHK(hipMemset(G.d_bounds, 0, nb * 2 + 16));
         HIPCHK(hipMemcpy(G.d_bounds, b.data(), nb * 2, hipMemcpyHostToDevice));
         S.bounds_u8 = (const unsigned char*)G.d_bounds;
         S.cells_u8  = (const uint2*)G.d_cells;
@@ -294,13 +297,17 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p)
         else
             L.stage = nullptr;
         HIPCHK(hipMemsetAsync(G.d_queue, 0, sizeof(unsigned), G.stream));
+        // the brick table goes through LDS when it fits (decomposition estimator, byte table <= 64 KiB)
+        const bool lds_bounds = G.use_lds_bounds && G.est == VP_EST_DECOMP && G.quant &&
+                                (size_t)S.bnx * S.bny * S.bnz <= (size_t)VP_LDS_BOUND_ENTRIES;
+        const unsigned bsz = lds_bounds ? VP_BLOCK_LDS : VP_BLOCK;
         unsigned waves  = (L.total_items + 63) / 64;
-        unsigned blocks = (waves + (VP_BLOCK / 64) - 1) / (VP_BLOCK / 64);
-        unsigned cap    = (unsigned)G.num_cu * G.blocks_per_cu;
+        unsigned blocks = (waves + (bsz / 64) - 1) / (bsz / 64);
+        unsigned cap    = (unsigned)G.num_cu * (lds_bounds ? 2u : G.blocks_per_cu);
         if (blocks > cap) blocks = cap;
         hipEvent_t e0 = get_event(), e1 = get_event();
         HIPCHK(hipEventRecord(e0, G.stream));
-        launch_render(S, L, G.est, G.rng, G.quant, G.count, (int)blocks, G.stream);
+        launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, (int)blocks, G.stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, G.stream));
         G.events.emplace_back(e0, e1);

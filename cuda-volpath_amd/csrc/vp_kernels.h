@@ -5,6 +5,8 @@
 #include "vp_device.h"
 
 #define VP_BLOCK 256
+#define VP_BLOCK_LDS 512              // workgroup size of the LDS-bound-table variant
+#define VP_LDS_BOUND_ENTRIES 32768     // (max,min) byte pairs staged in LDS: 64 KiB
 #define VP_CHUNK 256  // samples a wave takes from the global queue per atomic
 // the inner tracking loop of a wave runs until this many lanes are parked on an event, or until
 // a parked lane has waited this many steps
@@ -37,7 +39,7 @@ struct LaunchDev
     unsigned wait_lanes, wait_iters;  // inner-loop exit policy (VP_WAIT_LANES / VP_WAIT_ITERS)
 };
 
-void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int blocks, hipStream_t st);
+void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, int blocks, hipStream_t st);
 void launch_reduce(const LaunchDev& L, hipStream_t st);
 void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, hipStream_t st);
 void launch_pack_f32(const float* vol, float* cells, int nx, int ny, int nz, hipStream_t st);

@@ -34,9 +34,22 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-template <int EST, class RNG, bool QUANT, bool COUNT>
-__global__ __launch_bounds__(VP_BLOCK) void render_k(SceneDev S, LaunchDev L)
+// LDSB: the (max,min) brick table of the decomposition estimator is staged through LDS (BASELINE config 3:
+// 256^3 / 8^3 bricks = 32768 byte pairs = 64 KiB).  Those workgroups are 512 threads so that two of them
+// (2 x 64 KiB of the CU's 160 KiB) keep 16 waves per CU resident.
+template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB>
+__global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(SceneDev S, LaunchDev L)
 {
+    __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
+    if (LDSB)
+    {
+        // coalesced 16-byte loads of the table, 16-byte LDS stores
+        const uint4* src = reinterpret_cast<const uint4*>(S.bounds_u8);
+        uint4*       dst = reinterpret_cast<uint4*>(lds_bounds);
+        const int    n16 = (S.bnx * S.bny * S.bnz * 2 + 15) / 16;  // the device table is padded to 16 bytes
+        for (int w = threadIdx.x; w < n16; w += VP_BLOCK_LDS) dst[w] = src[w];
+        __syncthreads();
+    }
     const ParamDev& P = L.P;
     const f3    sun_dir   = f3{S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]};
     const f3    sun_power = f3{S.sun_power[0], S.sun_power[1], S.sun_power[2]};
@@ -273,7 +286,18 @@ __global__ __launch_bounds__(VP_BLOCK) void render_k(SceneDev S, LaunchDev L)
                 t_near    = fmaxf(t_near, 0.0f);
                 t_far     = fminf(tf, 0.05f);
                 float bx, by;
-                sample_bound<QUANT>(S, ro + rd * t_near, bx, by);
+                if (LDSB)
+                {
+                    f3  pl = to_local(S, ro + rd * t_near);
+                    int bi = axis_point(pl.x, S.nx) >> S.brick_shift;
+                    int bj = axis_point(pl.y, S.ny) >> S.brick_shift;
+                    int bk = axis_point(pl.z, S.nz) >> S.brick_shift;
+                    unsigned short v = lds_bounds[(unsigned)bi + __umul24((unsigned)S.bnx, (unsigned)bj + __umul24((unsigned)S.bny, (unsigned)bk))];
+                    bx = (float)(v & 0xffu) * VP_U8_SCALE;
+                    by = (float)(v >> 8) * VP_U8_SCALE;
+                }
+                else
+                    sample_bound<QUANT>(S, ro + rd * t_near, bx, by);
                 if (COUNT) c_bnd++;
                 float d_min = by;
                 d_max       = fmaxf(0.0001f, bx);
@@ -545,32 +569,41 @@ __global__ void test_density_k(SceneDev S, const float* pos, float* out, int n)
 }
 
 // ------------------------------------------------------------------ host-side launchers
-template <int EST, class RNG>
-static void launch_render2(const SceneDev& S, const LaunchDev& L, bool quant, bool count, int blocks, hipStream_t st)
+template <int EST, class RNG, bool LDSB>
+static void launch_render3(const SceneDev& S, const LaunchDev& L, bool quant, bool count, int blocks, hipStream_t st)
 {
+    const dim3 blk(LDSB ? VP_BLOCK_LDS : VP_BLOCK);
     if (quant)
     {
-        if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
-        else hipLaunchKernelGGL((render_k<EST, RNG, true, false>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+        if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB>), dim3(blocks), blk, 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB>), dim3(blocks), blk, 0, st, S, L);
     }
     else
     {
-        if (count) hipLaunchKernelGGL((render_k<EST, RNG, false, true>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
-        else hipLaunchKernelGGL((render_k<EST, RNG, false, false>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+        if (count) hipLaunchKernelGGL((render_k<EST, RNG, false, true, false>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, false, false, false>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
     }
 }
 
-void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int blocks, hipStream_t st)
+void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, int blocks, hipStream_t st)
 {
     if (est == EST_DECOMP)
     {
-        if (rng == RNG_PHILOX) launch_render2<EST_DECOMP, RngPhilox>(S, L, quant, count, blocks, st);
-        else launch_render2<EST_DECOMP, RngSamplerH>(S, L, quant, count, blocks, st);
+        if (lds_bounds && quant)
+        {
+            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, true>(S, L, quant, count, blocks, st);
+            else launch_render3<EST_DECOMP, RngSamplerH, true>(S, L, quant, count, blocks, st);
+        }
+        else
+        {
+            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, false>(S, L, quant, count, blocks, st);
+            else launch_render3<EST_DECOMP, RngSamplerH, false>(S, L, quant, count, blocks, st);
+        }
     }
     else
     {
-        if (rng == RNG_PHILOX) launch_render2<EST_GLOBAL, RngPhilox>(S, L, quant, count, blocks, st);
-        else launch_render2<EST_GLOBAL, RngSamplerH>(S, L, quant, count, blocks, st);
+        if (rng == RNG_PHILOX) launch_render3<EST_GLOBAL, RngPhilox, false>(S, L, quant, count, blocks, st);
+        else launch_render3<EST_GLOBAL, RngSamplerH, false>(S, L, quant, count, blocks, st);
     }
 }
 void launch_reduce(const LaunchDev& L, hipStream_t st)
