@@ -311,6 +311,21 @@ __device__ __forceinline__ bool intersect_box(f3 o, f3 d, const SceneDev& S, flo
     return smallest_tmax > largest_tmin && smallest_tmax >= 1e-3f;
 }
 
+// the same slab test with the reciprocal direction supplied (1/d is what intersectBox computes first; a ray
+// keeps its direction over many restart segments, so the three IEEE divides are hoisted out)
+__device__ __forceinline__ bool intersect_box_inv(f3 o, f3 invR, const SceneDev& S, float& tnear, float& tfar)
+{
+    f3 tbot = invR * (f3{S.bmin[0], S.bmin[1], S.bmin[2]} - o);
+    f3 ttop = invR * (f3{S.bmax[0], S.bmax[1], S.bmax[2]} - o);
+    f3 tmin = f3{fminf(ttop.x, tbot.x), fminf(ttop.y, tbot.y), fminf(ttop.z, tbot.z)};
+    f3 tmax = f3{fmaxf(ttop.x, tbot.x), fmaxf(ttop.y, tbot.y), fmaxf(ttop.z, tbot.z)};
+    float largest_tmin  = max3(tmin);
+    float smallest_tmax = min3(tmax);
+    tnear = largest_tmin;
+    tfar  = smallest_tmax;
+    return smallest_tmax > largest_tmin && smallest_tmax >= 1e-3f;
+}
+
 // Frame kernel.cu:557-573 (fabs(n.x) > 0.1 is a DOUBLE compare: equivalent to >= 0.1f in float)
 struct Frame
 {

@@ -37,7 +37,10 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
 // LDSB: the (max,min) brick table of the decomposition estimator is staged through LDS (BASELINE config 3:
 // 256^3 / 8^3 bricks = 32768 byte pairs = 64 KiB).  Those workgroups are 512 threads so that two of them
 // (2 x 64 KiB of the CU's 160 KiB) keep 16 waves per CU resident.
-template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB>
+// ACH: achromatic medium (sigma_t and albedo equal in all three channels): the three throughput channels stay
+// bitwise identical (same operations on the same values), so one is carried and the collision sums are
+// formed from one product, (m + m) + m, exactly as the three-channel expression evaluates.
+template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH>
 __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
@@ -68,6 +71,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
     RNG      rng;
     f3       ro = {}, rd = {};   // the ray being tracked (primary, or the shadow ray while ST_SHADOW)
     f3       pd = {};            // primary direction, kept while the shadow ray is tracked
+    f3       inv_rd = {};        // 1 / rd of the primary ray (decomposition set-up)
     f3       thr = {}, rad = {};
     int      nsc = 0;            // num_scatters (DECOMP) / depth i (GLOBAL)
     float    dist = 0, t_end = 0;  // position on the tracked ray; where the current free flight ends
@@ -145,11 +149,12 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
         // ---- sun contribution + phase-function sampling (kernel.cu:2188-2189,:2209-2210,:2301-2303)
         if (st == EV_NEE)
         {
-            rad = rad + sun_power * ((thr * ph) * nee_a);
+            rad = rad + sun_power * (((ACH ? f3{thr.x, thr.x, thr.x} : thr) * ph) * nee_a);
             Frame fr(pd);
             float r0 = rng.next();
             float r1 = rng.next();
             rd       = normalize(fr.to_world(hg_sample_local(phase_g, r0, r1)));
+            if (EST == EST_DECOMP) inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
             st       = ST_SETUP;
             if (EST == EST_GLOBAL) nsc++;
             if (nsc >= 800) st = EV_WRITE;  // max_depth kernel.cu:34, loop conditions :2015 / :1332
@@ -206,6 +211,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
                                 f3 dv   = f3{u, v, S.cam_z};
                                 rd = normalize(f3{dot(dv, f3{S.cam[0], S.cam[1], S.cam[2]}), dot(dv, f3{S.cam[4], S.cam[5], S.cam[6]}),
                                                   dot(dv, f3{S.cam[8], S.cam[9], S.cam[10]})});
+                                if (EST == EST_DECOMP) inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
                                 thr = f3{1.0f, 1.0f, 1.0f};
                                 rad = f3{0.0f, 0.0f, 0.0f};
                                 nsc = 0;
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
                 f3 bg;
                 if (nsc == 0 && dot(rd, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
                 else { bg = eval_envmap(S, rd); if (COUNT) c_env++; }
-                rad = rad + bg * thr;
+                rad = rad + bg * (ACH ? f3{thr.x, thr.x, thr.x} : thr);
                 st  = EV_WRITE;
             }
             // ---- path end: emit the sample (kernel.cu:2306-2316 / :1579-1589)
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
             {
                 // intersectSuperVolume kernel.cu:1626-1661 (quirks Q6, Q10): the bound is fetched before the hit test
                 float t_near, tf;
-                bool  hit = intersect_box(ro, rd, S, t_near, tf);
+                bool  hit = intersect_box_inv(ro, inv_rd, S, t_near, tf);
                 t_near    = fmaxf(t_near, 0.0f);
                 t_far     = fminf(tf, 0.05f);
                 float bx, by;
@@ -368,9 +374,34 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
                     if (shadow)
                     {
                         // kernel.cu:791-805
-                        if (!(terms & 1) && e < sig_t.x * den * inv_sigma) terms |= 1;
-                        if (!(terms & 2) && e < sig_t.y * den * inv_sigma) terms |= 2;
-                        if (!(terms & 4) && e < sig_t.z * den * inv_sigma) terms |= 4;
+                        if (ACH) terms = (e < sig_t.x * den * inv_sigma) ? 7 : terms;
+                        else
+                        {
+                            int t = terms;
+                            t |= (e < sig_t.x * den * inv_sigma) ? 1 : 0;
+                            t |= (e < sig_t.y * den * inv_sigma) ? 2 : 0;
+                            t |= (e < sig_t.z * den * inv_sigma) ? 4 : 0;
+                            terms = t;
+                        }
+                    }
+                    else if (ACH)
+                    {
+                        // history-aware collision probabilities kernel.cu:2107-2134 (quirk Q8), one channel carried
+                        float a_t = sig_t.x * den, a_s = sig_s.x * den;
+                        if (EST == EST_DECOMP) { a_t = a_t - sigma_c; a_s = a_s - sigma_c; }
+                        float a_n  = sigma_t_prime - a_t;
+                        float mt   = __builtin_fabsf(a_t * thr.x), mn = __builtin_fabsf(a_n * thr.x);
+                        float Ps   = (mt + mt) + mt;
+                        float Pn   = (mn + mn) + mn;
+                        float c    = Ps + Pn;
+                        bool  real = e * c < Ps;
+                        float f    = inv_sigma_t * c / (real ? Ps : Pn);
+                        thr.x      = thr.x * ((real ? a_s : a_n) * f);
+                        if (real)
+                        {
+                            ro = p;
+                            st = EV_SCATTER;
+                        }
                     }
                     else
                     {
@@ -569,41 +600,51 @@ __global__ void test_density_k(SceneDev S, const float* pos, float* out, int n)
 }
 
 // ------------------------------------------------------------------ host-side launchers
-template <int EST, class RNG, bool LDSB>
-static void launch_render3(const SceneDev& S, const LaunchDev& L, bool quant, bool count, int blocks, hipStream_t st)
+template <int EST, class RNG, bool LDSB, bool ACH>
+static void launch_render4(const SceneDev& S, const LaunchDev& L, bool quant, bool count, int blocks, hipStream_t st)
 {
     const dim3 blk(LDSB ? VP_BLOCK_LDS : VP_BLOCK);
     if (quant)
     {
-        if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB>), dim3(blocks), blk, 0, st, S, L);
-        else hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB>), dim3(blocks), blk, 0, st, S, L);
+        if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB, ACH>), dim3(blocks), blk, 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB, ACH>), dim3(blocks), blk, 0, st, S, L);
     }
     else
     {
-        if (count) hipLaunchKernelGGL((render_k<EST, RNG, false, true, false>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
-        else hipLaunchKernelGGL((render_k<EST, RNG, false, false, false>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+        if (count) hipLaunchKernelGGL((render_k<EST, RNG, false, true, false, ACH>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, false, false, false, ACH>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
     }
+}
+template <int EST, class RNG, bool LDSB>
+static void launch_render3(const SceneDev& S, const LaunchDev& L, bool quant, bool count, bool ach, int blocks, hipStream_t st)
+{
+    if (ach) launch_render4<EST, RNG, LDSB, true>(S, L, quant, count, blocks, st);
+    else launch_render4<EST, RNG, LDSB, false>(S, L, quant, count, blocks, st);
 }
 
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, int blocks, hipStream_t st)
 {
+    // achromatic medium: identical extinction and albedo in the three channels (e.g. preset #13, host.cpp:1308)
+    const ParamDev& P = L.P;
+    const bool ach = P.sigma_t[0] == P.sigma_t[1] && P.sigma_t[1] == P.sigma_t[2] && P.albedo[0] == P.albedo[1] &&
+                     P.albedo[1] == P.albedo[2];
     if (est == EST_DECOMP)
     {
         if (lds_bounds && quant)
         {
-            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, true>(S, L, quant, count, blocks, st);
-            else launch_render3<EST_DECOMP, RngSamplerH, true>(S, L, quant, count, blocks, st);
+            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, true>(S, L, quant, count, ach, blocks, st);
+            else launch_render3<EST_DECOMP, RngSamplerH, true>(S, L, quant, count, ach, blocks, st);
         }
         else
         {
-            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, false>(S, L, quant, count, blocks, st);
-            else launch_render3<EST_DECOMP, RngSamplerH, false>(S, L, quant, count, blocks, st);
+            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, false>(S, L, quant, count, ach, blocks, st);
+            else launch_render3<EST_DECOMP, RngSamplerH, false>(S, L, quant, count, ach, blocks, st);
         }
     }
     else
     {
-        if (rng == RNG_PHILOX) launch_render3<EST_GLOBAL, RngPhilox, false>(S, L, quant, count, blocks, st);
-        else launch_render3<EST_GLOBAL, RngSamplerH, false>(S, L, quant, count, blocks, st);
+        if (rng == RNG_PHILOX) launch_render3<EST_GLOBAL, RngPhilox, false>(S, L, quant, count, ach, blocks, st);
+        else launch_render3<EST_GLOBAL, RngSamplerH, false>(S, L, quant, count, ach, blocks, st);
     }
 }
 void launch_reduce(const LaunchDev& L, hipStream_t st)

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvolpath_hip.so")
+LIB_PATH = os.environ.get("VOLPATH_LIB", os.path.join(os.path.dirname(_HERE), "libvolpath_hip.so"))  # override: A/B builds
 
 EST_GLOBAL, EST_DECOMP = 0, 1
 RNG_SAMPLERH, RNG_PHILOX = 0, 1
