@@ -17,12 +17,18 @@
 #include <vector>
 
 #include "../../include/volpath.h"
-#include "vp_bounds.h"
 #include "vp_kernels.h"
 
 namespace
 {
 using namespace vp;
+
+// host.cpp:1098-1101: diffusion_iters = ceil(search_radius / (2.0f / width))
+int bound_radius(int nx, float search_radius)
+{
+    float cell_size = 2.0f / (float)nx;
+    return (int)std::ceil(search_radius / cell_size);
+}
 
 struct State
 {
@@ -167,35 +173,36 @@ int do_init_volume(const void* h_volume, vp_extent ext, bool quantized, const vp
     if (quantized) launch_pack_u8((const unsigned char*)d_raw, (uint2*)G.d_cells, nx, ny, nz, G.stream);
     else launch_pack_f32((const float*)d_raw, (float*)G.d_cells, nx, ny, nz, G.stream);
     HIPCHK(hipGetLastError());
-    // bound table (CPU, overlaps the upload)
+    // bound table: three separable max/min passes + brick reduction on the GPU (replaces host.cpp:1088-1267)
     G.brick  = G.brick_next;
     G.radius = bound_radius(nx, 0.05f /* search_radius kernel.cu:151 */) + (G.brick > 1 ? 1 : 0);
     int shift = 0;
     while ((1 << shift) < G.brick) shift++;
     S.brick_shift = shift;
     S.bnx = (nx + G.brick - 1) / G.brick; S.bny = (ny + G.brick - 1) / G.brick; S.bnz = (nz + G.brick - 1) / G.brick;
-    const size_t nb = (size_t)S.bnx * S.bny * S.bnz;
+    const size_t nb    = (size_t)S.bnx * S.bny * S.bnz;
+    const size_t psize = quantized ? 2 : 8;
+    void *d_ta = nullptr, *d_tb = nullptr;
+    HIPCHK(hipMalloc(&d_ta, n * psize));
+    HIPCHK(hipMalloc(&d_tb, n * psize));
+    HIPCHK(hipMalloc(&G.d_bounds, nb * psize + 16));  // padded: the LDS stage copies whole 16-byte words
+    HIPCHK(hipMemsetAsync(G.d_bounds, 0, nb * psize + 16, G.stream));
+    launch_build_bounds(d_raw, quantized, G.d_bounds, d_ta, d_tb, nx, ny, nz, G.radius, G.brick, G.stream);
+    HIPCHK(hipGetLastError());
     if (quantized)
     {
-        std::vector<uint8_t> b(nb * 2);
-        build_bounds_u8((const uint8_t*)h_volume, nx, ny, nz, G.radius, G.brick, b.data());
-        HIPCHK(hipMalloc(&G.d_bounds, nb * 2 + 16));  // padded: the LDS stage copies whole 16-byte words
-        HIPCHK(hipMemset(G.d_bounds, 0, nb * 2 + 16));
-        HIPCHK(hipMemcpy(G.d_bounds, b.data(), nb * 2, hipMemcpyHostToDevice));
         S.bounds_u8 = (const unsigned char*)G.d_bounds;
         S.cells_u8  = (const uint2*)G.d_cells;
     }
     else
     {
-        std::vector<float> b(nb * 2);
-        build_bounds_f32((const float*)h_volume, nx, ny, nz, G.radius, G.brick, b.data());
-        HIPCHK(hipMalloc(&G.d_bounds, nb * 8));
-        HIPCHK(hipMemcpy(G.d_bounds, b.data(), nb * 8, hipMemcpyHostToDevice));
         S.bounds_f32 = (const float*)G.d_bounds;
         S.cells_f32  = (const float*)G.d_cells;
     }
     HIPCHK(hipStreamSynchronize(G.stream));  // caller may free h_volume on return (host.cpp:1343)
     HIPCHK(hipFree(d_raw));
+    HIPCHK(hipFree(d_ta));
+    HIPCHK(hipFree(d_tb));
     S.linear      = G.linear ? 1 : 0;
     G.have_volume = true;
     return VP_OK;

@@ -44,6 +44,8 @@ void launch_reduce(const LaunchDev& L, hipStream_t st);
 void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, hipStream_t st);
 void launch_pack_f32(const float* vol, float* cells, int nx, int ny, int nz, hipStream_t st);
 void launch_opacity(const SceneDev& S, bool quant, const float dir[3], float* out, hipStream_t st);
+void launch_build_bounds(const void* d_vol, bool quant, void* d_out, void* d_tmp_a, void* d_tmp_b, int nx, int ny, int nz, int radius, int brick,
+                         hipStream_t st);
 void launch_julia(unsigned char* grid, int n, hipStream_t st);
 void launch_scale(float4* dst, const float4* src, int size, float s, hipStream_t st);
 void launch_gamma(float4* dst, const float4* src, int size, float s, float inv_gamma, hipStream_t st);

@@ -497,6 +497,78 @@ __global__ void pack_cells_f32_k(const float* vol, float* cells, int nx, int ny,
     q[1] = make_float4(at(i, j, k1), at(i1, j, k1), at(i, j1, k1), at(i1, j1, k1));
 }
 
+// ---- local (max,min) bound table (compute_volume_value_bound_, host.cpp:1088-1267) on the GPU.
+// Per voxel, max and min of the density over the (2r+1)^3 window clipped to the grid; max/min filters are
+// separable, so three streaming passes (x, y, z) of a 1-D window each; then one entry per brick.
+// Pairs are packed (max | min << 8) for uchar volumes and float2 for float volumes.
+struct PairU8
+{
+    typedef unsigned char  T;
+    typedef unsigned short P;
+    static __device__ __forceinline__ P make(T mx, T mn) { return (P)((unsigned)mx | ((unsigned)mn << 8)); }
+    static __device__ __forceinline__ T mx(P p) { return (T)(p & 0xffu); }
+    static __device__ __forceinline__ T mn(P p) { return (T)(p >> 8); }
+};
+struct PairF32
+{
+    typedef float  T;
+    typedef float2 P;
+    static __device__ __forceinline__ P make(T mx, T mn) { return make_float2(mx, mn); }
+    static __device__ __forceinline__ T mx(P p) { return p.x; }
+    static __device__ __forceinline__ T mn(P p) { return p.y; }
+};
+template <class PR>
+__global__ __launch_bounds__(256) void bounds_init_k(const typename PR::T* vol, typename PR::P* out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = PR::make(vol[i], vol[i]);
+}
+// one 1-D pass along `axis` (stride in elements, extent na); threads run along x so every read is coalesced
+template <class PR>
+__global__ __launch_bounds__(256) void bounds_pass_k(const typename PR::P* in, typename PR::P* out, int nx, int ny, int nz, int axis, int r)
+{
+    size_t n   = (size_t)nx * ny * nz;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    int    i = (int)(idx % nx), j = (int)((idx / nx) % ny), k = (int)(idx / ((size_t)nx * ny));
+    int    o = axis == 0 ? i : (axis == 1 ? j : k), na = axis == 0 ? nx : (axis == 1 ? ny : nz);
+    size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)nx : (size_t)nx * ny);
+    int    lo = o - r < 0 ? 0 : o - r, hi = o + r > na - 1 ? na - 1 : o + r;
+    const typename PR::P* base = in + idx - (size_t)o * stride;
+    typename PR::P v  = base[(size_t)lo * stride];
+    typename PR::T mx = PR::mx(v), mn = PR::mn(v);
+    for (int q = lo + 1; q <= hi; q++)
+    {
+        v = base[(size_t)q * stride];
+        typename PR::T a = PR::mx(v), b = PR::mn(v);
+        mx = a > mx ? a : mx;
+        mn = b < mn ? b : mn;
+    }
+    out[idx] = PR::make(mx, mn);
+}
+template <class PR>
+__global__ __launch_bounds__(256) void bounds_brick_k(const typename PR::P* in, typename PR::P* out, int nx, int ny, int nz, int brick, int bnx,
+                                                       int bny, int bnz)
+{
+    size_t nb  = (size_t)bnx * bny * bnz;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nb) return;
+    int bi = (int)(idx % bnx), bj = (int)((idx / bnx) % bny), bk = (int)(idx / ((size_t)bnx * bny));
+    int i1 = min((bi + 1) * brick, nx), j1 = min((bj + 1) * brick, ny), k1 = min((bk + 1) * brick, nz);
+    typename PR::P v  = in[(size_t)(bi * brick) + (size_t)nx * ((size_t)(bj * brick) + (size_t)ny * (bk * brick))];
+    typename PR::T mx = PR::mx(v), mn = PR::mn(v);
+    for (int k = bk * brick; k < k1; k++)
+        for (int j = bj * brick; j < j1; j++)
+            for (int i = bi * brick; i < i1; i++)
+            {
+                v = in[(size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k)];
+                typename PR::T a = PR::mx(v), b = PR::mn(v);
+                mx = a > mx ? a : mx;
+                mn = b < mn ? b : mn;
+            }
+    out[idx] = PR::make(mx, mn);  // .x = max, .y = min (host.cpp:1141-1144)
+}
+
 // _precompute_opacity kernel.cu:483-524 with intersect_box :453-481; one thread per voxel
 template <bool QUANT>
 __global__ __launch_bounds__(256) void opacity_k(SceneDev S, f3 light_dir, float* out)
@@ -669,6 +741,30 @@ void launch_opacity(const SceneDev& S, bool quant, const float dir[3], float* ou
     dim3   g((unsigned)((n + 255) / 256));
     if (quant) hipLaunchKernelGGL(opacity_k<true>, g, dim3(256), 0, st, S, d, out);
     else hipLaunchKernelGGL(opacity_k<false>, g, dim3(256), 0, st, S, d, out);
+}
+template <class PR>
+static void build_bounds_t(const void* d_vol, void* d_out, void* d_tmp_a, void* d_tmp_b, int nx, int ny, int nz, int radius, int brick, hipStream_t st)
+{
+    typedef typename PR::P P;
+    size_t   n = (size_t)nx * ny * nz;
+    unsigned g = (unsigned)((n + 255) / 256);
+    P *a = (P*)d_tmp_a, *b = (P*)d_tmp_b;
+    hipLaunchKernelGGL(bounds_init_k<PR>, dim3(g), dim3(256), 0, st, (const typename PR::T*)d_vol, a, n);
+    for (int axis = 0; axis < 3; axis++)
+    {
+        hipLaunchKernelGGL(bounds_pass_k<PR>, dim3(g), dim3(256), 0, st, (const P*)a, b, nx, ny, nz, axis, radius);
+        P* t = a; a = b; b = t;
+    }
+    int bnx = (nx + brick - 1) / brick, bny = (ny + brick - 1) / brick, bnz = (nz + brick - 1) / brick;
+    size_t nb = (size_t)bnx * bny * bnz;
+    hipLaunchKernelGGL(bounds_brick_k<PR>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const P*)a, (P*)d_out, nx, ny, nz, brick, bnx, bny, bnz);
+}
+// d_tmp_a / d_tmp_b: two scratch buffers of nx*ny*nz pairs (2 B uchar, 8 B float)
+void launch_build_bounds(const void* d_vol, bool quant, void* d_out, void* d_tmp_a, void* d_tmp_b, int nx, int ny, int nz, int radius, int brick,
+                         hipStream_t st)
+{
+    if (quant) build_bounds_t<PairU8>(d_vol, d_out, d_tmp_a, d_tmp_b, nx, ny, nz, radius, brick, st);
+    else build_bounds_t<PairF32>(d_vol, d_out, d_tmp_a, d_tmp_b, nx, ny, nz, radius, brick, st);
 }
 void launch_julia(unsigned char* grid, int n, hipStream_t st)
 {

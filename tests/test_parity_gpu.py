@@ -227,3 +227,19 @@ def test_cli_render_matches_oracle_ppm(vp, oracle, tmp_path):
     assert raw.startswith(head)
     got = np.frombuffer(raw[len(head):], np.uint8).reshape(48, 64, 3)
     assert np.array_equal(got, expect)
+
+
+@pytest.mark.parametrize("quantized", [True, False])
+@pytest.mark.parametrize("brick", [1, 4])
+def test_gpu_bound_table_builder(vp, oracle, quantized, brick):
+    """H1 on the GPU (separable max/min passes + brick merge) against the oracle's brute-force windows,
+    on a ragged non-cubic volume."""
+    rng = np.random.default_rng(11)
+    nz, ny, nx = 9, 14, 120
+    g = rng.random((nz, ny, nx), dtype=np.float32)
+    g[rng.random(g.shape) < 0.6] = 0
+    grid = (g * 255).astype(np.uint8) if quantized else g
+    vp.init_volume(grid, brick=brick)
+    tab, b, r = vp.bound_table(quantized)
+    assert b == brick and r == oracle.bound_radius(nx) + (1 if brick > 1 else 0) and r >= 3
+    assert np.array_equal(tab, oracle.bounds(grid, r, brick))
