@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3ref", "c1"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3ref", "c1", "c4s"])
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
     ap.add_argument("--rng", default="philox", choices=["philox", "samplerh"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

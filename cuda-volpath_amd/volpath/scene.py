@@ -21,6 +21,11 @@ WORKLOADS = {
                name="julia256_800x600_global_majorant"),
     "c3": dict(n=256, width=800, height=600, est=EST_DECOMP, brick=8, chromatic=False,
                name="julia256_800x600_decomp_brick8"),
+    # BASELINE configs[3]/[4] name the WDAS cloud through vdbloader; neither the data set nor OpenVDB exists in this
+    # image, so this is a FLAGGED SYNTHETIC STAND-IN of the same shape: a 512^3 dense uchar grid (Julia set),
+    # chromatic medium (preset #1, host.cpp:1296), 1280x720, decomposition tracking with a 16^3-brick table in LDS
+    "c4s": dict(n=512, width=1280, height=720, est=EST_DECOMP, brick=16, chromatic=True,
+                name="STANDIN_julia512_1280x720_chromatic_decomp_brick16"),
     "c3ref": dict(n=256, width=800, height=600, est=EST_DECOMP, brick=1, chromatic=False,
                   name="julia256_800x600_decomp_refbounds"),
 }
