@@ -243,3 +243,73 @@ def test_gpu_bound_table_builder(vp, oracle, quantized, brick):
     tab, b, r = vp.bound_table(quantized)
     assert b == brick and r == oracle.bound_radius(nx) + (1 if brick > 1 else 0) and r >= 3
     assert np.array_equal(tab, oracle.bounds(grid, r, brick))
+
+
+@pytest.mark.parametrize("case", ["ragged_image", "one_pixel", "tiny_volume", "isotropic_absorbing", "zero_density",
+                                  "negative_g", "late_frames_philox", "off_centre_box"])
+def test_edge_cases_bit_exact(vp, oracle, case):
+    global W, H
+    W0, H0 = W, H
+    try:
+        grid, kw, frames, est, rng, box, env = oracle.julia(32), {}, range(3), 1, 0, None, scenes.synthetic_env()
+        preset = None
+        if case == "ragged_image":
+            W, H = 70, 45           # partial 8x8 tiles on both edges
+        elif case == "one_pixel":
+            W, H = 1, 1
+        elif case == "tiny_volume":
+            grid = np.array([[[0, 255], [128, 7], [3, 90]]], np.uint8)  # nz=1, ny=3, nx=2
+            kw = dict(density=5.0)
+        elif case == "isotropic_absorbing":
+            kw = dict(g=0.0, albedo=(0.5, 0.7, 0.9), sigma_t=(1.0, 0.8, 0.6), density=300.0)
+        elif case == "zero_density":
+            kw = dict(density=0.0)
+        elif case == "negative_g":
+            kw = dict(g=-0.4)
+        elif case == "late_frames_philox":
+            frames, rng, est = range(100000, 100003), 1, 0
+        elif case == "off_centre_box":
+            box = ((-0.3, -1.1, 0.2), (1.2, 0.4, 1.9))
+            env = np.full((1, 1, 4), 0.25, np.float32)   # 1x1 environment
+        osc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, box=box, estimator=est,
+                                 rng_mode=rng, seed=(7, 7))
+        oP = oracle.default_param(W, H, **kw)
+        vP = vp.make_param(W, H, **kw)
+        vp.init_volume(grid, box=box, brick=1, linear=True)
+        vp.init_envmap(env)
+        vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+        vp.set_camera()
+        vp.set_estimator(est)
+        vp.set_rng(rng, (7, 7))
+        vp.set_shard(0, 1)
+        ref, _ = _oracle_frames(osc, oP, frames)
+        buf = vp.DeviceBuffer(W, H)
+        vp.render_frames(buf.ptr, frames[0], len(frames), vP)
+        got = buf.download()
+        buf.free()
+        assert np.array_equal(got, ref, equal_nan=True), f"{case}: max abs diff {np.nanmax(np.abs(got - ref))}"
+    finally:
+        W, H = W0, H0
+
+
+def test_bad_arguments_are_rejected(vp):
+    grid = vp.julia_volume(8)
+    vp.init_volume(grid)
+    vp.init_envmap(scenes.synthetic_env())
+    vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+    vp.set_camera()
+    vp.set_estimator(1)
+    P = vp.make_param(16, 16)
+    buf = vp.DeviceBuffer(16, 16)
+    with pytest.raises(vp.VolpathError):
+        vp.render_frames(buf.ptr, 0, 0, P)          # no frames
+    with pytest.raises(vp.VolpathError):
+        vp.render_frames(None, 0, 1, P)             # null accumulator
+    with pytest.raises(vp.VolpathError):
+        vp.render_frames(buf.ptr, 20, 1, P)         # frame > 10 without precompute_opacity (kernel.cu:2183)
+    with pytest.raises(vp.VolpathError):
+        vp.render_frames(buf.ptr, 0, 1, vp.make_param(70000, 4))   # sampler.h packs x<<16|y
+    vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+    vp.render_frames(buf.ptr, 20, 1, P)
+    assert np.isfinite(buf.download()).all()
+    buf.free()
