@@ -68,7 +68,7 @@ struct State
 };
 State G;
 
-constexpr size_t kMaxStageBytes = (size_t)1 << 30;  // 1 GiB of per-sample staging per launch
+size_t kMaxStageBytes = (size_t)1 << 30;  // 1 GiB of per-sample staging per launch (VP_STAGE_MB overrides)
 
 int fail(int code, const char* fmt, ...)
 {
@@ -115,6 +115,7 @@ int ensure_device()
     // tuning knobs (performance only; results never depend on them)
     if (const char* e = getenv("VP_WAIT_LANES")) G.wait_lanes = (unsigned)atoi(e);
     if (const char* e = getenv("VP_WAIT_ITERS")) G.wait_iters = (unsigned)atoi(e);
+    if (const char* e = getenv("VP_STAGE_MB")) kMaxStageBytes = (size_t)atoi(e) << 20;
     if (const char* e = getenv("VP_BLOCKS_PER_CU")) G.blocks_per_cu = (unsigned)atoi(e);
     if (const char* e = getenv("VP_NO_LDS_BOUNDS")) G.use_lds_bounds = atoi(e) == 0;
     G.dev_ready = true;

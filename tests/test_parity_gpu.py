@@ -313,3 +313,48 @@ def test_bad_arguments_are_rejected(vp):
     vp.render_frames(buf.ptr, 20, 1, P)
     assert np.isfinite(buf.download()).all()
     buf.free()
+
+
+def test_lds_brick_table_with_opacity_frames(vp, oracle):
+    """BASELINE config 3 in miniature: 8^3 bricks (LDS-staged table), frames across the frame-11 estimator
+    switch (quirk Q5), Philox streams."""
+    grid = oracle.julia(64)
+    osc, oP, vP = _setup(vp, oracle, grid, 1, 1, brick=8, key=(3, 1))
+    osc.precompute_opacity()
+    vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+    ref, cnt = _oracle_frames(osc, oP, range(8, 14))
+    assert cnt["opacity_lookups"] > 0
+    buf = vp.DeviceBuffer(W, H)
+    vp.render_frames(buf.ptr, 8, 6, vP)
+    assert np.array_equal(buf.download(), ref)
+    buf.free()
+
+
+def test_multi_launch_batches_in_subprocess(oracle, tmp_path):
+    """vp_render_frames splits long renders into several launches when the staging buffer is capped;
+    the split must not change a bit (run in a child process so that VP_STAGE_MB is read at device init)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import volpath as vp, scenes
+vp.set_device(0)
+grid = vp.julia_volume(32)
+vp.init_volume(grid); vp.init_envmap(scenes.synthetic_env()); vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+vp.set_camera(); vp.set_estimator(0); vp.set_rng(1, (5, 6))
+P = vp.make_param(64, 48); buf = vp.DeviceBuffer(64, 48)
+vp.render_frames(buf.ptr, 0, 40, P)
+n = vp.render_time_ms()[1]
+np.save(%r, buf.download()); print("launches", n)
+""" % (os.path.join(root, "cuda-volpath_amd"), os.path.join(root, "tests"), str(tmp_path / "out.npy"))
+    outs = []
+    for mb in ("1", "512"):   # 1 MiB of staging = 21 frames of 64x48 per launch -> two launches
+        env = dict(os.environ, VP_STAGE_MB=mb)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append((np.load(str(tmp_path / "out.npy")), int(r.stdout.split()[-1])))
+    assert outs[0][1] > outs[1][1] == 1
+    assert np.array_equal(outs[0][0], outs[1][0])
