@@ -1,5 +1,5 @@
 """Digest of scripts/profile_bench.sh output: per-launch averages of the render kernel."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, re, sys
 out = sys.argv[1]
 res = {}
 ks = glob.glob(f"{out}/kt/**/*kernel_stats.csv", recursive=True)
@@ -13,7 +13,8 @@ for d in ("fetch", "write", "sq", "tcc"):
         agg = collections.defaultdict(float); disp = set()
         for r in csv.DictReader(open(f)):
             # the timed variant only: template args <EST, RNG, QUANT, COUNT=false>
-            if "render_k" in r["Kernel_Name"] and "false>" in r["Kernel_Name"]:
+            m = re.search(r"render_k<([^>]*)>", r["Kernel_Name"])
+            if m and m.group(1).split(",")[3].strip() == "false":
                 agg[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
         n = max(len(disp), 1)
         res[d] = {"launches": len(disp), "per_launch": {k: v / n for k, v in agg.items()}}
