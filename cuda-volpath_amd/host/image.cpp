@@ -30,7 +30,7 @@ inline Rgbe to_rgbe(const Pixel& c)
 }
 }  // namespace
 
-Image::Image() : Image(0, 0) {}
+Image::Image() { resize(0, 0); }
 Image::Image(int w, int h) { resize(w, h); }
 Image::~Image() {}
 
