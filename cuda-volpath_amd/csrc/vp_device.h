@@ -92,43 +92,57 @@ struct RngSamplerH
         return result;
     }
     __device__ __forceinline__ float next() { return u2f(0x3f800000u | (word() >> 9)) - 1.0f; }
+    __device__ __forceinline__ void prepare2() {}
 };
 
-// Philox4x32-10 (Salmon et al. 2011), counter = (x, y, frame, draw/4), key = (k0, k1)
+// Philox2x32-10 (Salmon et al., SC'11).  Draw n of sample (x, y, frame) is word n&1 of
+// philox2x32_10(counter = (n>>1, x<<16|y), key = (frame ^ k0) + k1).  Pairs are generated at ONE place per
+// tracking step (prepare2), so the ten multiply rounds run once per step for the whole wave instead of
+// wherever a lane happens to run dry.
 struct RngPhilox
 {
-    unsigned cx, cy, cf, n, k0, k1;
-    unsigned b0, b1, b2, b3;
+    unsigned pix, key, pair;  // next pair index to generate
+    unsigned b0, b1, b2;      // queue of generated, not yet consumed words
+    int      have;
     __device__ __forceinline__ void init(unsigned px, unsigned py, unsigned frame, unsigned key0, unsigned key1)
     {
-        cx = px; cy = py; cf = frame; n = 0; k0 = key0; k1 = key1;
-        b0 = b1 = b2 = b3 = 0;
+        pix = (px << 16) | py; key = (frame ^ key0) + key1; pair = 0; have = 0;
+        b0 = b1 = b2 = 0;
     }
-    __device__ __forceinline__ void block(unsigned blk)
+    __device__ __forceinline__ void gen(unsigned& o0, unsigned& o1)
     {
-        unsigned c0 = cx, c1 = cy, c2 = cf, c3 = blk, ka = k0, kb = k1;
+        unsigned c0 = pair, c1 = pix, k = key;
 #pragma unroll
         for (int r = 0; r < 10; r++)
         {
-            unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
-            unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-            unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ ka;
-            unsigned n1 = (unsigned)p1;
-            unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ kb;
-            unsigned n3 = (unsigned)p0;
-            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-            ka += 0x9E3779B9u;
-            kb += 0xBB67AE85u;
+            unsigned long long p = (unsigned long long)0xD256D193u * c0;
+            unsigned n0 = (unsigned)(p >> 32) ^ k ^ c1;
+            c1 = (unsigned)p;
+            c0 = n0;
+            k += 0x9E3779B9u;
         }
-        b0 = c0; b1 = c1; b2 = c2; b3 = c3;
+        o0 = c0; o1 = c1;
+        pair++;
+    }
+    // make sure the next two draws are buffered
+    __device__ __forceinline__ void prepare2()
+    {
+        if (have < 2)
+        {
+            unsigned n0, n1;
+            gen(n0, n1);
+            if (have == 0) { b0 = n0; b1 = n1; }
+            else { b1 = n0; b2 = n1; }
+            have += 2;
+        }
     }
     __device__ __forceinline__ unsigned word()
     {
-        unsigned q = n & 3u;
-        if (q == 0) block(n >> 2);
-        n++;
-        unsigned w = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
-        return w;
+        if (have == 0) { gen(b0, b1); have = 2; }
+        unsigned r = b0;
+        b0 = b1; b1 = b2;
+        have--;
+        return r;
     }
     __device__ __forceinline__ float next() { return u2f(0x3f800000u | (word() >> 9)) - 1.0f; }
 };

@@ -339,6 +339,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
             if (st == ST_TRACK || st == ST_SHADOW)
             {
                 const bool shadow = st == ST_SHADOW;
+                rng.prepare2();                          // both draws of this step come from buffered words
                 dist += -logf_(rng.next()) * inv_sigma;  // kernel.cu:2085 / :784
                 if (dist >= t_end || (shadow && terms == 7))
                 {

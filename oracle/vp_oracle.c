@@ -61,33 +61,28 @@ uint32_t vpo_hash(uint32_t seed)
     return seed;
 }
 
-/* Random123 philox4x32-10 (Salmon et al., SC'11): the counter-based generator north_star asks
- * for in place of sampler.h. */
-void vpo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+/* Random123 philox2x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): the
+ * counter-based generator north_star asks for in place of sampler.h.  One call = two 32-bit words. */
+void vpo_philox2x32_10(const uint32_t ctr[2], uint32_t key, uint32_t out[2])
 {
-    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
-    uint32_t k0 = key[0], k1 = key[1];
+    uint32_t c0 = ctr[0], c1 = ctr[1], k = key;
     for (int r = 0; r < 10; r++)
     {
-        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        uint32_t n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        uint32_t n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
+        uint64_t p  = (uint64_t)0xD256D193u * c0;
+        uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
+        c1 = (uint32_t)p;
+        c0 = n0;
+        k += 0x9E3779B9u;
     }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    out[0] = c0; out[1] = c1;
 }
 
 typedef struct
 {
     int      mode;
     uint32_t sx, sy;         /* sampler.h state */
-    uint32_t ctr[4], key[2]; /* philox: ctr = (x, y, frame, block) */
-    uint32_t buf[4];
+    uint32_t ctr[2], key;    /* philox: ctr = (draw pair index, x<<16|y), key = (frame ^ seed0) + seed1 */
+    uint32_t buf[2];
     uint32_t n; /* draws so far */
     uint64_t* draws;
 } rng_t;
@@ -118,8 +113,8 @@ static void rng_init(rng_t* r, const vpo_scene* S, uint32_t px, uint32_t py, uin
     }
     else
     {
-        r->ctr[0] = px; r->ctr[1] = py; r->ctr[2] = frame; r->ctr[3] = 0;
-        r->key[0] = S->seed[0]; r->key[1] = S->seed[1];
+        r->ctr[0] = 0; r->ctr[1] = (px << 16) | py;
+        r->key = (frame ^ S->seed[0]) + S->seed[1];
     }
 }
 
@@ -131,12 +126,13 @@ static inline float rng_next(rng_t* r)
         w = samplerh_next(&r->sx, &r->sy);
     else
     {
-        if ((r->n & 3u) == 0)
+        /* draw n is word n&1 of the pair with index n>>1 */
+        if ((r->n & 1u) == 0)
         {
-            r->ctr[3] = r->n >> 2;
-            vpo_philox4x32_10(r->ctr, r->key, r->buf);
+            r->ctr[0] = r->n >> 1;
+            vpo_philox2x32_10(r->ctr, r->key, r->buf);
         }
-        w = r->buf[r->n & 3u];
+        w = r->buf[r->n & 1u];
     }
     r->n++;
     if (r->draws) (*r->draws)++;

@@ -61,7 +61,7 @@ typedef struct
     /* estimator / rng */
     int      estimator;
     int      rng_mode;
-    uint32_t seed[2]; /* Philox key */
+    uint32_t seed[2]; /* Philox: key = (frame ^ seed[0]) + seed[1] */
 } vpo_scene;
 
 typedef struct
@@ -86,7 +86,7 @@ void vpo_render_sample(const vpo_scene* S, const vpo_param* P, int x, int y, int
 uint32_t vpo_hash(uint32_t seed);
 void     vpo_rng_stream(int mode, uint32_t x, uint32_t y, uint32_t frame, uint32_t k0, uint32_t k1, int n,
                         float* out);
-void     vpo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void     vpo_philox2x32_10(const uint32_t ctr[2], uint32_t key, uint32_t out[2]);
 void     vpo_julia_voxelize(int n, uint8_t* grid);
 int      vpo_bound_radius(int nx, float search_radius);
 void     vpo_bounds_u8(const uint8_t* grid, int nx, int ny, int nz, int radius, int brick, uint8_t* out);

@@ -1,0 +1,86 @@
+// Instruction issue-rate microbenchmark for gfx950: N independent chains of one instruction per wave,
+// 8 waves per SIMD, timed with s_memtime.  Prints cycles per wave-instruction per SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int OP>
+__global__ __launch_bounds__(256) void rate_k(unsigned long long* out, float seed, int iters)
+{
+    float    a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    unsigned u0 = threadIdx.x * 2654435761u + 1u, u1 = u0 + 17u, u2 = u0 + 31u, u3 = u0 + 51u, u4 = u0 + 71u, u5 = u0 + 91u, u6 = u0 + 111u, u7 = u0 + 131u;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; i++)
+    {
+#define R8F(stmt) { float& x = a0; stmt } { float& x = a1; stmt } { float& x = a2; stmt } { float& x = a3; stmt } { float& x = a4; stmt } { float& x = a5; stmt } { float& x = a6; stmt } { float& x = a7; stmt }
+#define R8U(stmt) { unsigned& x = u0; stmt } { unsigned& x = u1; stmt } { unsigned& x = u2; stmt } { unsigned& x = u3; stmt } { unsigned& x = u4; stmt } { unsigned& x = u5; stmt } { unsigned& x = u6; stmt } { unsigned& x = u7; stmt }
+        if (OP == 0) { R8F(asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x));) }
+        if (OP == 1) { R8U(asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 2) { R8U(asm volatile("v_mul_u32_u24 %0, %0, %0" : "+v"(x));) }
+        if (OP == 3) { R8F(asm volatile("v_floor_f32 %0, %0" : "+v"(x));) }
+        if (OP == 4) { R8F(asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(x));) }
+        if (OP == 5) { R8F(asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(x));) }
+        if (OP == 6) { R8F(asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(x));) }
+        if (OP == 7) { R8F(asm volatile("v_rcp_f32 %0, %0" : "+v"(x));) }
+        if (OP == 8) { R8F(asm volatile("v_div_fixup_f32 %0, %0, %0, %0" : "+v"(x));) }
+        if (OP == 9) { R8U(asm volatile("v_alignbit_b32 %0, %0, %0, 13" : "+v"(x));) }
+        if (OP == 10) { R8U(asm volatile("v_xor_b32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 11) { R8F(asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(x));) }
+        if (OP == 12) { R8F(asm volatile("v_mul_f32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 13) { R8F(asm volatile("v_max_f32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 14) { R8U(asm volatile("v_mad_u32_u24 %0, %0, %0, %0" : "+v"(x));) }
+        if (OP == 15) { R8U(asm volatile("v_bfe_u32 %0, %0, 3, 5" : "+v"(x));) }
+        if (OP == 16) { R8U(asm volatile("v_max_i32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 17) { R8F(asm volatile("v_cmp_lt_f32 vcc, %0, %0" :: "v"(x) : "vcc");) }
+        if (OP == 18) { R8F(asm volatile("v_fract_f32 %0, %0" : "+v"(x));) }
+        if (OP == 19) { R8F(asm volatile("v_sqrt_f32 %0, %0" : "+v"(x));) }
+        if (OP == 20) { R8F(asm volatile("v_log_f32 %0, %0" : "+v"(x));) }
+        if (OP == 21) { R8F(asm volatile("v_add_f32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 22) { R8U(asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(x));) }
+        if (OP == 23) { R8U(asm volatile("v_sub_u32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_0" : "+v"(x));) }
+        if (OP == 24) { R8F(asm volatile("v_frexp_mant_f32 %0, %0" : "+v"(x));) }
+        if (OP == 25) { R8F(asm volatile("v_ldexp_f32 %0, %0, 3" : "+v"(x));) }
+        if (OP == 26) { R8U(asm volatile("v_mul_hi_u32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 27) { R8F(asm volatile("v_div_scale_f32 %0, vcc, %0, %0, %0" : "+v"(x) :: "vcc");) }
+        if (OP == 28) { R8F(asm volatile("v_div_fmas_f32 %0, %0, %0, %0" : "+v"(x) :: "vcc");) }
+        if (OP == 29) { R8F(asm volatile("v_fmac_f32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 30) { R8F(asm volatile("v_exp_f32 %0, %0" : "+v"(x));) }
+        if (OP == 31) { R8F(asm volatile("v_rndne_f32 %0, %0" : "+v"(x));) }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7);
+    if (s == 123.456f) out[1] = 1;
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+}
+template <int OP>
+int run(const char* name, unsigned long long* d, int waves_per_simd)
+{
+    const int iters = 2000;
+    // one CU-filling launch: blocks of 256 threads (4 waves = 1 per SIMD) x waves_per_simd per CU x 256 CUs
+    hipLaunchKernelGGL(rate_k<OP>, dim3(256 * waves_per_simd), dim3(256), 0, 0, d, 1.5f, iters);
+    CHK(hipDeviceSynchronize());
+    unsigned long long h[2];
+    CHK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+    // memtime ticks at 100 MHz on gfx9 (constant clock); convert with the shader clock estimate below
+    double ticks = (double)h[0];
+    printf("%-22s waves/SIMD %d: %8.0f ticks for %d x 8 inst/wave -> %.3f ticks per wave-inst per SIMD\n", name, waves_per_simd, ticks, iters,
+           ticks / (iters * 8.0 * waves_per_simd));
+    return 0;
+}
+int main()
+{
+    unsigned long long* d;
+    CHK(hipMalloc(&d, 16));
+    for (int w : {1, 2, 4})
+    {
+#define RUN(op, nm) run<op>(nm, d, w)
+        RUN(0, "v_fma_f32"); RUN(12, "v_mul_f32"); RUN(21, "v_add_f32"); RUN(29, "v_fmac_f32"); RUN(13, "v_max_f32"); RUN(1, "v_mul_lo_u32"); RUN(26, "v_mul_hi_u32");
+        RUN(2, "v_mul_u32_u24"); RUN(14, "v_mad_u32_u24"); RUN(3, "v_floor_f32"); RUN(18, "v_fract_f32"); RUN(31, "v_rndne_f32"); RUN(4, "v_cvt_i32_f32");
+        RUN(5, "v_cvt_f32_i32"); RUN(6, "v_cvt_f32_ubyte0"); RUN(7, "v_rcp_f32"); RUN(19, "v_sqrt_f32"); RUN(20, "v_log_f32"); RUN(30, "v_exp_f32");
+        RUN(27, "v_div_scale_f32"); RUN(28, "v_div_fmas_f32"); RUN(8, "v_div_fixup_f32"); RUN(9, "v_alignbit_b32"); RUN(10, "v_xor_b32"); RUN(22, "v_lshlrev_b32");
+        RUN(11, "v_cndmask_b32"); RUN(15, "v_bfe_u32"); RUN(16, "v_max_i32"); RUN(17, "v_cmp_lt_f32"); RUN(23, "v_sub_u32_sdwa"); RUN(24, "v_frexp_mant_f32");
+        RUN(25, "v_ldexp_f32");
+    }
+    return 0;
+}

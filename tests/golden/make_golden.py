@@ -37,11 +37,10 @@ def ref_anchors():
                                            "zero_scatter_pixel_fraction": 0.88, "p90_scatters": 13.9,
                                            "p99_scatters": 48.9},
         "bound_radius": {"32": 1, "64": 2, "128": 4, "256": 7, "512": 13},
-        "philox4x32_10_random123_kat": [
-            {"ctr": [0, 0, 0, 0], "key": [0, 0], "out": [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]},
-            {"ctr": [0xffffffff] * 4, "key": [0xffffffff] * 2, "out": [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]},
-            {"ctr": [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], "key": [0xa4093822, 0x299f31d0],
-             "out": [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]}],
+        "philox2x32_10_random123_kat": [
+            {"ctr": [0, 0], "key": 0, "out": [0xff1dae59, 0x6cd10df2]},
+            {"ctr": [0xffffffff, 0xffffffff], "key": 0xffffffff, "out": [0x2c3f628b, 0xab4fd7ad]},
+            {"ctr": [0x243f6a88, 0x85a308d3], "key": 0x13198a2e, "out": [0xdd7ce038, 0xf62a4c12]}],
     }
     json.dump(a, open(os.path.join(HERE, "ref_anchors.json"), "w"), indent=1)
 

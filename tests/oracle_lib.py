@@ -185,10 +185,10 @@ def rng_stream(mode, x, y, frame, n, key=(0, 0)):
 
 
 def philox(ctr, key):
-    c = (C.c_uint32 * 4)(*ctr)
-    k = (C.c_uint32 * 2)(*key)
-    o = (C.c_uint32 * 4)()
-    lib().vpo_philox4x32_10(c, k, o)
+    """Philox2x32-10: ctr = (c0, c1), key = one word -> two words"""
+    c = (C.c_uint32 * 2)(*ctr)
+    o = (C.c_uint32 * 2)()
+    lib().vpo_philox2x32_10(c, C.c_uint32(key), o)
     return list(o)
 
 

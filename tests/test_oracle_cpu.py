@@ -22,12 +22,12 @@ def test_hash_and_cudarng_match_reference_anchors(oracle):
 
 
 def test_philox_random123_kat(oracle):
-    for kat in ANCH["philox4x32_10_random123_kat"]:
+    for kat in ANCH["philox2x32_10_random123_kat"]:
         assert oracle.philox(kat["ctr"], kat["key"]) == kat["out"]
-    # draw n of stream (x,y,frame) = word n%4 of block (x,y,frame,n//4)
+    # draw n of sample (x,y,frame) = word n%2 of philox2x32_10((n//2, x<<16|y), (frame ^ k0) + k1)
     s = oracle.rng_stream(oracle.RNG_PHILOX, 3, 5, 7, 8, key=(11, 22))
     for n in range(8):
-        w = oracle.philox([3, 5, 7, n // 4], [11, 22])[n % 4]
+        w = oracle.philox([n // 2, (3 << 16) | 5], ((7 ^ 11) + 22) & 0xffffffff)[n % 2]
         assert s[n] == np.float32(np.uint32(0x3f800000 | (w >> 9)).view(np.float32) - np.float32(1.0))
 
 
