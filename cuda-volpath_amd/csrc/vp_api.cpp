@@ -108,8 +108,8 @@ int ensure_device()
     HIPCHK(hipStreamCreateWithFlags(&G.own_stream, hipStreamNonBlocking));
     if (!G.stream) G.stream = G.own_stream;
     HIPCHK(hipMalloc((void**)&G.d_queue, 256));
-    HIPCHK(hipMalloc((void**)&G.d_counters, 8 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(G.d_counters, 0, 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void**)&G.d_counters, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(G.d_counters, 0, 16 * sizeof(unsigned long long)));
     G.S.sun_cos = 94.0f / sqrtf(94.0f * 94.0f + 0.45f * 0.45f);                    // kernel.cu:1263
     G.S.cam_z   = (float)(-1.0f / tan((double)54.43f * 0.00872664626));             // kernel.cu:1981-1985
     // tuning knobs (performance only; results never depend on them)
@@ -478,13 +478,14 @@ int vp_read_counters(vp_counters* out, int reset)
     int rc = ensure_device();
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(G.stream));
-    unsigned long long h[8];
+    unsigned long long h[16];
     HIPCHK(hipMemcpy(h, G.d_counters, sizeof h, hipMemcpyDeviceToHost));
     if (out)
     {
         memset(out, 0, sizeof *out);
         out->samples = h[0]; out->density_lookups = h[1]; out->density_loads = h[1]; out->bound_lookups = h[2];
         out->opacity_lookups = h[3]; out->env_lookups = h[4]; out->scatters = h[5];
+        if (getenv("VP_DEBUG_COUNTERS")) fprintf(stderr, "[vp] wave-iterations %llu, active lane-steps %llu (%.1f per iteration), slow-path visits %llu (every %.1f iterations), shadow lane-steps %llu\n", h[6], h[7], h[6] ? (double)h[7] / h[6] : 0.0, h[8], h[8] ? (double)h[6] / h[8] : 0.0, h[9]);
     }
     if (reset) HIPCHK(hipMemset(G.d_counters, 0, sizeof h));
     return VP_OK;

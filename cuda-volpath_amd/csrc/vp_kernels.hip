@@ -81,6 +81,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
     int      terms = 0;
 
     unsigned long long c_den = 0, c_bnd = 0, c_opa = 0, c_env = 0, c_sca = 0, c_smp = 0;
+    unsigned long long d_iter = 0, d_act = 0, d_outer = 0, d_shadow = 0;  // debug (lane 0 counts wave events)
 
     const unsigned lane = threadIdx.x & 63u;
     unsigned chunk_next = 0, chunk_end = 0;  // wave-uniform
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
 
     for (;;)
     {
+        if (COUNT && lane == 0) d_outer++;
         // =========================================================== slow path: events
         // ---- collision: direct lighting set-up (kernel.cu:2161-2217 / :1458-1491)
         if (st == EV_SCATTER)
@@ -282,6 +284,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
             unsigned long long wm = __ballot(!active && !(st == ST_DONE && exhausted));
             unsigned nwait = (unsigned)__popcll(wm);
             if (am == 0ull || nwait >= L.wait_lanes || (nwait > 0u && iter >= (int)L.wait_iters)) break;
+            if (COUNT && lane == 0) { d_iter++; d_act += (unsigned)__popcll(am); d_shadow += (unsigned)__popcll(__ballot(st == ST_SHADOW)); }
             if (!active) continue;
 
             if (EST == EST_DECOMP && st == ST_SETUP)
@@ -439,9 +442,9 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
     if (COUNT)
     {
         // wave reduction, one atomic per counter per wave
-        unsigned long long vals[6] = {c_smp, c_den, c_bnd, c_opa, c_env, c_sca};
+        unsigned long long vals[10] = {c_smp, c_den, c_bnd, c_opa, c_env, c_sca, d_iter, d_act, d_outer, d_shadow};
 #pragma unroll
-        for (int q = 0; q < 6; q++)
+        for (int q = 0; q < 10; q++)
         {
             unsigned long long v = vals[q];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
