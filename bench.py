@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
     ap.add_argument("--rng", default="philox", choices=["philox", "samplerh"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-image", default=None, help="rank 0 saves the summed HDR image (.npy) -- used by tests")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,10 +91,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # VP_BENCH_REHEARSAL=1: every rank on GPU 0 and the reduce over gloo through host memory -- lets the N>1
+    # code path (sharding, reduce, timing, JSON) be rehearsed on a one-GPU box.  Never used for reported numbers.
+    rehearsal = os.environ.get("VP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import volpath as vp
     from volpath import scene as vscene
@@ -104,8 +113,9 @@ def main():
     spp_step = args.spp * world
     total_steps = args.warmup + args.steps
     rng_mode = vp.RNG_PHILOX if args.rng == "philox" else vp.RNG_SAMPLERH
+    count_frames = 4 if args.workload == "c2" else 16  # frames of the (untimed) work-counter pass
     P, info = vscene.setup(args.workload, rng_mode=rng_mode, rank=rank, world=world,
-                           last_frame=spp_step * total_steps)
+                           last_frame=max(spp_step * total_steps, count_frames))
     W, H = P.width, P.height
 
     def barrier():
@@ -120,7 +130,7 @@ def main():
         # work counters (untimed, counting kernel variant): per-sample lookups of THIS build
         vp.enable_counters(True)
         vp.read_counters(reset=True)
-        vp.render_frames(acc.data_ptr(), 0, 16 if args.workload != "c2" else 4, P)
+        vp.render_frames(acc.data_ptr(), 0, count_frames, P)
         counters = vp.read_counters(reset=True)
         vp.enable_counters(False)
         bytes_per_sample = algorithmic_bytes_per_sample(counters)
@@ -128,7 +138,11 @@ def main():
         def step(i):
             acc.zero_()
             vp.render_frames(acc.data_ptr(), i * spp_step, spp_step, P)
-            if world > 1:
+            if world > 1 and rehearsal:
+                host = acc.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                acc.copy_(host)
+            elif world > 1:
                 dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI
             if rank == 0:
                 image.add_(acc)
@@ -144,7 +158,7 @@ def main():
         dt = time.perf_counter() - t0
         kern_ms, launches = vp.render_time_ms(reset=True)
 
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    t = torch.tensor([dt], device=torch.device("cpu") if rehearsal else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -178,6 +192,11 @@ def main():
                          "lookups_per_sample": {k: counters[k] / max(counters["samples"], 1) for k in
                                                 ("density_lookups", "bound_lookups", "opacity_lookups", "env_lookups", "scatters")}},
         }
+        if args.dump_image:
+            import numpy as np
+            np.save(args.dump_image, image.cpu().numpy())
+        if rehearsal:
+            out["config"]["parallelism"] += " (REHEARSAL: all ranks on one GPU, gloo)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

@@ -358,3 +358,32 @@ np.save(%r, buf.download()); print("launches", n)
         outs.append((np.load(str(tmp_path / "out.npy")), int(r.stdout.split()[-1])))
     assert outs[0][1] > outs[1][1] == 1
     assert np.array_equal(outs[0][0], outs[1][0])
+
+
+def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path):
+    """bench.py's N>1 path end to end on this one-GPU box (both ranks on GPU 0, reduce over gloo): the
+    2-rank image of frames [0,8) must equal the 1-rank image bit for bit, and the JSON line must be well formed."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--workload", "c1"]
+    r1 = subprocess.run([sys.executable, bench, "--gpus", "1", "--spp", "8", "--dump-image", one] + common,
+                        capture_output=True, text=True, cwd=root)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, VP_BENCH_REHEARSAL="1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port), bench, "--gpus", "2", "--spp", "4",
+                         "--dump-image", two] + common, capture_output=True, text=True, cwd=root, env=env)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    line1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    line2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    for line, n in ((line1, 1), (line2, 2)):
+        assert line["n_gpus"] == n and line["scaling"] == "weak" and line["unit"] == "Msamples/s" and line["value"] > 0
+        assert line["config"]["spp_per_step"] == 8 and set(line["roofline"]) >= {"bound", "achieved", "peak", "frac", "traffic"}
+    assert np.array_equal(np.load(one), np.load(two))
