@@ -246,13 +246,14 @@ def test_gpu_bound_table_builder(vp, oracle, quantized, brick):
 
 
 @pytest.mark.parametrize("case", ["ragged_image", "one_pixel", "tiny_volume", "isotropic_absorbing", "zero_density",
-                                  "negative_g", "late_frames_philox", "off_centre_box"])
+                                  "negative_g", "late_frames_philox", "off_centre_box", "global_chromatic",
+                                  "global_chromatic_philox", "global_point_filter"])
 def test_edge_cases_bit_exact(vp, oracle, case):
     global W, H
     W0, H0 = W, H
     try:
         grid, kw, frames, est, rng, box, env = oracle.julia(32), {}, range(3), 1, 0, None, scenes.synthetic_env()
-        preset = None
+        preset, linear = None, True
         if case == "ragged_image":
             W, H = 70, 45           # partial 8x8 tiles on both edges
         elif case == "one_pixel":
@@ -268,14 +269,20 @@ def test_edge_cases_bit_exact(vp, oracle, case):
             kw = dict(g=-0.4)
         elif case == "late_frames_philox":
             frames, rng, est = range(100000, 100003), 1, 0
+        elif case in ("global_chromatic", "global_chromatic_philox"):
+            est, rng = 0, (1 if case.endswith("philox") else 0)
+            kw = dict(g=0.5, albedo=(0.95, 0.8, 0.6), sigma_t=(1.0, 0.7, 0.45), density=120.0)
+            frames = range(5)
+        elif case == "global_point_filter":
+            est, linear = 0, False
         elif case == "off_centre_box":
             box = ((-0.3, -1.1, 0.2), (1.2, 0.4, 1.9))
             env = np.full((1, 1, 4), 0.25, np.float32)   # 1x1 environment
         osc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, box=box, estimator=est,
-                                 rng_mode=rng, seed=(7, 7))
+                                 rng_mode=rng, seed=(7, 7), linear=linear)
         oP = oracle.default_param(W, H, **kw)
         vP = vp.make_param(W, H, **kw)
-        vp.init_volume(grid, box=box, brick=1, linear=True)
+        vp.init_volume(grid, box=box, brick=1, linear=linear)
         vp.init_envmap(env)
         vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
         vp.set_camera()
