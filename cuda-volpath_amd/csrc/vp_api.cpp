@@ -446,7 +446,7 @@ int vp_synchronize(void)
 }
 int vp_set_estimator(int est)
 {
-    if (est != VP_EST_GLOBAL && est != VP_EST_DECOMP) return fail(VP_E_ARG, "unknown estimator %d", est);
+    if (est != VP_EST_GLOBAL && est != VP_EST_DECOMP && est != VP_EST_BOUNDED) return fail(VP_E_ARG, "unknown estimator %d", est);
     G.est = est;
     return VP_OK;
 }

@@ -20,7 +20,7 @@
 namespace vp
 {
 // same values as the VP_EST_* / VP_RNG_* enums of include/volpath.h
-constexpr int EST_GLOBAL = 0, EST_DECOMP = 1;
+constexpr int EST_GLOBAL = 0, EST_DECOMP = 1, EST_BOUNDED = 2;
 constexpr int RNG_SAMPLERH = 0, RNG_PHILOX = 1;
 
 // one render launch: frames [frame0, frame0+nframes) x the 8x8 pixel tiles this rank owns

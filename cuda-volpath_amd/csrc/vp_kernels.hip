@@ -53,6 +53,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
         for (int w = threadIdx.x; w < n16; w += VP_BLOCK_LDS) dst[w] = src[w];
         __syncthreads();
     }
+    constexpr bool LOCAL = EST != EST_GLOBAL;  // the two local-majorant estimators share the segment logic
     const ParamDev& P = L.P;
     const f3    sun_dir   = f3{S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]};
     const f3    sun_power = f3{S.sun_power[0], S.sun_power[1], S.sun_power[2]};
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
     f3       pd = {};            // primary direction, kept while the shadow ray is tracked
     f3       inv_rd = {};        // 1 / rd of the primary ray (decomposition set-up)
     f3       thr = {}, rad = {};
-    int      nsc = 0;            // num_scatters (DECOMP) / depth i (GLOBAL)
+    int      nsc = 0;            // num_scatters (DECOMP, BOUNDED) / depth i (GLOBAL)
+    int      seg = 0;            // BOUNDED only: loop index i, one per tracked segment (kernel.cu:1716)
     float    dist = 0, t_end = 0;  // position on the tracked ray; where the current free flight ends
     float    t_far = 0, distc = 0, inv_sigma = 0, inv_sigma_t = 0, sigma_t_prime = 0, sigma_c = 0;
     float    cur_density = 0, d_max = 0, phase_g = 0, ph = 0;
@@ -95,11 +97,11 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
         if (st == EV_SCATTER)
         {
             if (COUNT) c_sca++;
-            if (EST == EST_DECOMP) nsc++;  // num_scatters += !through, kernel.cu:2146
+            if (LOCAL) nsc++;  // num_scatters += !through, kernel.cu:2146
             // "to match passive result": post-increment count (DECOMP :2168) / i-4 (GLOBAL :1465)
-            float s2 = hyperion_s((EST == EST_DECOMP) ? (nsc - 5) : (nsc - 4));
+            float s2 = hyperion_s((LOCAL) ? (nsc - 5) : (nsc - 4));
             float dp2, stp2;
-            if (EST == EST_DECOMP)
+            if (LOCAL)
             {
                 float reduction2 = (1.0f - s2) + s2 * (1.0f - P.g);
                 dp2              = reduction2 * density;
@@ -156,10 +158,12 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
             float r0 = rng.next();
             float r1 = rng.next();
             rd       = normalize(fr.to_world(hg_sample_local(phase_g, r0, r1)));
-            if (EST == EST_DECOMP) inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
+            if (LOCAL) inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
             st       = ST_SETUP;
             if (EST == EST_GLOBAL) nsc++;
-            if (nsc >= 800) st = EV_WRITE;  // max_depth kernel.cu:34, loop conditions :2015 / :1332
+            if (EST == EST_BOUNDED) seg++;
+            // max_depth kernel.cu:34, loop conditions :2015 / :1332 / :1716
+            if ((EST == EST_BOUNDED ? seg : nsc) >= 800) st = EV_WRITE;
         }
 #pragma unroll 1
         for (int rep = 0; rep < 4; rep++)
@@ -213,10 +217,11 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
                                 f3 dv   = f3{u, v, S.cam_z};
                                 rd = normalize(f3{dot(dv, f3{S.cam[0], S.cam[1], S.cam[2]}), dot(dv, f3{S.cam[4], S.cam[5], S.cam[6]}),
                                                   dot(dv, f3{S.cam[8], S.cam[9], S.cam[10]})});
-                                if (EST == EST_DECOMP) inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
+                                if (LOCAL) inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
                                 thr = f3{1.0f, 1.0f, 1.0f};
                                 rad = f3{0.0f, 0.0f, 0.0f};
                                 nsc = 0;
+                                seg = 0;
                                 st  = ST_SETUP;
                                 if (COUNT) c_smp++;
                             }
@@ -260,7 +265,8 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
             if (st == EV_WRITE)
             {
                 f3     r    = rad * P.brightness;
-                float  heat = (EST == EST_DECOMP) ? (float)nsc : (float)((double)nsc * 0.001);
+                // heat: num_scatters (:2307) or loop index * 0.001 in double (:1581, :1942)
+                float  heat = (EST == EST_DECOMP) ? (float)nsc : (float)((double)(EST == EST_BOUNDED ? seg : nsc) * 0.001);
                 float4 v    = make_float4(fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f), fmaxf(r.z, 0.0f), heat);
                 if (L.stage) L.stage[item] = v;
                 else
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
 #pragma unroll 1
         for (int iter = 0;; iter++)
         {
-            bool active = (st == ST_TRACK) || (st == ST_SHADOW) || (EST == EST_DECOMP && st == ST_SETUP);
+            bool active = (st == ST_TRACK) || (st == ST_SHADOW) || (LOCAL && st == ST_SETUP);
             unsigned long long am = __ballot(active);
             unsigned long long wm = __ballot(!active && !(st == ST_DONE && exhausted));
             unsigned nwait = (unsigned)__popcll(wm);
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
             if (COUNT && lane == 0) { d_iter++; d_act += (unsigned)__popcll(am); d_shadow += (unsigned)__popcll(__ballot(st == ST_SHADOW)); }
             if (!active) continue;
 
-            if (EST == EST_DECOMP && st == ST_SETUP)
+            if (LOCAL && st == ST_SETUP)
             {
                 // intersectSuperVolume kernel.cu:1626-1661 (quirks Q6, Q10): the bound is fetched before the hit test
                 float t_near, tf;
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
                     cur_density     = reduction * density;
                     sigma_t_prime   = max_sig * cur_density * d_max;
                     inv_sigma_t     = 1.0f / sigma_t_prime;
-                    if (d_min > 0.0f)
+                    if (EST == EST_DECOMP && d_min > 0.0f)
                     {
                         // analog decomposition tracking kernel.cu:2048-2054 (quirk Q7)
                         sigma_c       = min_sig * cur_density * d_min;
@@ -352,13 +358,14 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
                         nee_a = f3{(float)(1 - (terms & 1)), (float)(1 - ((terms >> 1) & 1)), (float)(1 - ((terms >> 2) & 1))};
                         st    = EV_NEE;
                     }
-                    else if (EST == EST_DECOMP)
+                    else if (LOCAL)
                     {
                         bool through = fminf(distc, dist) >= t_far;  // kernel.cu:2145
                         if (through)
                         {
-                            ro = ro + rd * t_far;  // tracking restart kernel.cu:2151-2155
+                            ro = ro + rd * t_far;  // tracking restart kernel.cu:2151-2155 / :1809-1813
                             st = ST_SETUP;
+                            if (EST == EST_BOUNDED && ++seg >= 800) st = EV_WRITE;  // `continue` still counts, :1716
                         }
                         else
                         {
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
                     {
                         // history-aware collision probabilities kernel.cu:2107-2134 (quirk Q8), one channel carried
                         float a_t = sig_t.x * den, a_s = sig_s.x * den;
-                        if (EST == EST_DECOMP) { a_t = a_t - sigma_c; a_s = a_s - sigma_c; }
+                        if (LOCAL) { a_t = a_t - sigma_c; a_s = a_s - sigma_c; }
                         float a_n  = sigma_t_prime - a_t;
                         float mt   = __builtin_fabsf(a_t * thr.x), mn = __builtin_fabsf(a_n * thr.x);
                         float Ps   = (mt + mt) + mt;
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
                         // history-aware collision probabilities kernel.cu:2107-2134 (quirk Q8)
                         f3 sigma_t_den = sig_t * den;
                         f3 sigma_s_den = sig_s * den;
-                        if (EST == EST_DECOMP)
+                        if (LOCAL)
                         {
                             f3 sc       = f3{sigma_c, sigma_c, sigma_c};
                             sigma_t_den = sigma_t_den - sc;
@@ -716,6 +723,12 @@ void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool
             if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, false>(S, L, quant, count, ach, blocks, st);
             else launch_render3<EST_DECOMP, RngSamplerH, false>(S, L, quant, count, ach, blocks, st);
         }
+    }
+    else if (est == EST_BOUNDED)
+    {
+        // the dead reference variant: no LDS specialisation, it is there for completeness
+        if (rng == RNG_PHILOX) launch_render3<EST_BOUNDED, RngPhilox, false>(S, L, quant, count, ach, blocks, st);
+        else launch_render3<EST_BOUNDED, RngSamplerH, false>(S, L, quant, count, ach, blocks, st);
     }
     else
     {

@@ -20,7 +20,7 @@
 static void usage()
 {
     printf("volpath_render [--julia N | --bin file.bin | --vdb file.vdb] [--size W H] [--spp N] [--preset 0..12]\n"
-           "               [--density D] [--g G] [--estimator decomp|global] [--brick B] [--rng samplerh|philox]\n"
+           "               [--density D] [--g G] [--estimator decomp|global|bounded] [--brick B] [--rng samplerh|philox]\n"
            "               [--sun X Y] [--batch F] [--out name(.ppm|.hdr)]\n");
 }
 
@@ -28,7 +28,8 @@ int main(int argc, char** argv)
 {
     int         julia = 128, W = 400, H = 300, spp = 16, preset = 12, brick = 1, batch = 0;
     float       density = 800.0f, g = 0.877f, sunx = 0.5f, suny = 0.2f;
-    bool        global_est = false, philox = false;
+    bool        philox = false;
+    int         est = VP_EST_DECOMP;
     std::string bin, vdb, out = "output0.ppm";
     for (int i = 1; i < argc; i++)
     {
@@ -42,7 +43,12 @@ int main(int argc, char** argv)
         else if (a == "--preset") { need(1); preset = atoi(argv[++i]); }
         else if (a == "--density") { need(1); density = (float)atof(argv[++i]); }
         else if (a == "--g") { need(1); g = (float)atof(argv[++i]); }
-        else if (a == "--estimator") { need(1); global_est = !strcmp(argv[++i], "global"); }
+        else if (a == "--estimator")
+        {
+            need(1);
+            const char* e = argv[++i];
+            est = !strcmp(e, "global") ? VP_EST_GLOBAL : !strcmp(e, "bounded") ? VP_EST_BOUNDED : VP_EST_DECOMP;
+        }
         else if (a == "--brick") { need(1); brick = atoi(argv[++i]); }
         else if (a == "--rng") { need(1); philox = !strcmp(argv[++i], "philox"); }
         else if (a == "--sun") { need(2); sunx = (float)atof(argv[++i]); suny = (float)atof(argv[++i]); }
@@ -88,7 +94,7 @@ int main(int argc, char** argv)
     printf("sun power = %f, %f, %f\n", sky.sun_power.x, sky.sun_power.y, sky.sun_power.z);
     set_sun(&sky.sun_dir.x, &sky.sun_power.x);
 
-    vp_set_estimator(global_est ? VP_EST_GLOBAL : VP_EST_DECOMP);
+    vp_set_estimator(est);
     vp_set_rng(philox ? VP_RNG_PHILOX : VP_RNG_SAMPLERH, 0x9E3779B9u, 0x85EBCA6Bu);
 
     // ---- frame buffer (CudaFrameBuffer host.cpp:358-389)
@@ -102,7 +108,7 @@ int main(int argc, char** argv)
     vp_dim3 block = {8, 8, 1}, grid = {(unsigned)(W + 7) / 8, (unsigned)(H + 7) / 8, 1};
     for (int s = 0; s < spp;)
     {
-        if (s > 10 || (batch > 0 && s + batch > 11)) { static bool done = false; if (!done && !global_est) { precompute_opacity(&sky.sun_dir.x); done = true; } }
+        if (s > 10 || (batch > 0 && s + batch > 11)) { static bool done = false; if (!done && est == VP_EST_DECOMP) { precompute_opacity(&sky.sun_dir.x); done = true; } }
         if (batch > 0)
         {
             int n = std::min(batch, spp - s);

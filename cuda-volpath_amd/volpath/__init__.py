@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VOLPATH_LIB", os.path.join(os.path.dirname(_HERE), "libvolpath_hip.so"))  # override: A/B builds
 
-EST_GLOBAL, EST_DECOMP = 0, 1
+EST_GLOBAL, EST_DECOMP, EST_BOUNDED = 0, 1, 2
 RNG_SAMPLERH, RNG_PHILOX = 0, 1
 
 # every symbol include/volpath.h declares (tests check the library exports each one)

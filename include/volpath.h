@@ -102,7 +102,9 @@ enum
 };
 
 enum { VP_EST_GLOBAL = 0, /* __d_render, kernel.cu:1285-1591: global majorant (BASELINE config 2) */
-       VP_EST_DECOMP = 1  /* __d_render_bounded_decomp, kernel.cu:1958-2318: the reference's live kernel */ };
+       VP_EST_DECOMP = 1, /* __d_render_bounded_decomp, kernel.cu:1958-2318: the reference's live kernel */
+       VP_EST_BOUNDED = 2 /* __d_render_bounded, kernel.cu:1667-1952: local majorant, no control component,
+                             800 tracked segments at most, heat = segments * 0.001, never reads the opacity volume */ };
 enum { VP_RNG_SAMPLERH = 0, /* src/sampler.h bit-compatible streams (parity mode) */
        VP_RNG_PHILOX   = 1  /* Philox2x32-10, counter = (draw/2, x<<16|y), key = (frame ^ key0) + key1 */ };
 

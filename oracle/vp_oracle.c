@@ -735,6 +735,119 @@ static void sample_decomp(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
     out[3] = (float)num_scatters;
 }
 
+/* ---------------------------------------------- A3: __d_render_bounded -- */
+/* kernel.cu:1667-1952: the local-majorant tracker without the control component.  Dead in the reference
+ * (its launch is commented out at :2368) but part of the same TU.  Against A1 it differs in four places:
+ * the loop is bounded by the segment index i < max_depth (:1716), a transmitted segment counts as an
+ * iteration (`continue`, :1812), the heat channel is i * 0.001 (:1942), and there is no opacity-volume branch. */
+static void sample_bounded(const vpo_scene* S, const vpo_param* P, uint32_t x, uint32_t y, int spp, float out[4],
+                           vpo_counters* C)
+{
+    const float density    = P->density;
+    const float brightness = P->brightness;
+    f3 boxMin = mk3(S->box_min[0], S->box_min[1], S->box_min[2]);
+    f3 boxMax = mk3(S->box_max[0], S->box_max[1], S->box_max[2]);
+    f3 sun_dir   = mk3(S->sun_dir[0], S->sun_dir[1], S->sun_dir[2]);
+    f3 sun_power = mk3(S->sun_power[0], S->sun_power[1], S->sun_power[2]);
+
+    rng_t rng;
+    rng_init(&rng, S, x, y, (uint32_t)spp, &C->rng_draws);
+    f3 cr_o, cr_d;
+    camera_ray(S, P, x, y, &cr_o, &cr_d);
+
+    f3 radiance   = mk3(0, 0, 0);
+    f3 throughput = mk3(1, 1, 1);
+    f3    sigma_t_spectral = mk3(P->sigma_t[0], P->sigma_t[1], P->sigma_t[2]);
+    f3    sigma_s_spectral = mul3(sigma_t_spectral, mk3(P->albedo[0], P->albedo[1], P->albedo[2]));
+    float max_sigma_t      = max_of3(sigma_t_spectral);
+
+    int num_scatters = 0;
+    int i;
+    for (i = 0; i < 800; i++) /* max_depth :34 */
+    {
+        float t_near, t_far, d_min, d_max;
+        int   hit = intersect_super_volume(S, cr_o, cr_d, boxMin, boxMax, &t_near, &t_far, &d_min, &d_max, C);
+        (void)d_min;
+        if (!hit)
+        {
+            radiance = add3(radiance, mul3(background(S, cr_d, num_scatters, C), throughput)); /* :1724-1731 */
+            break;
+        }
+        f3    pos;
+        float dist = t_near;
+
+        /* :1737-1751 */
+        float s = hyperion_s(num_scatters - 5);
+        float g = (1.0f - s) * P->g;
+        float reduction_factor = (1.0f - s) + s * (1.0f - P->g);
+        float density_prime = reduction_factor * density;
+        float sigma_t_prime = max_sigma_t * density_prime * d_max;
+        float inv_sigma     = 1.0f / sigma_t_prime;
+
+        int through = 0;
+        for (;;)
+        {
+            dist += -vpo_logf(rng_next(&rng)) * inv_sigma; /* :1757 */
+            pos = add3(cr_o, muls(cr_d, dist));
+            if (dist >= t_far)
+            {
+                through = 1;
+                break;
+            }
+            /* :1766-1795 */
+            float den            = vol_sigma_t(S, pos, density_prime, C);
+            f3    sigma_t_den    = muls(sigma_t_spectral, den);
+            f3    sigma_s_den    = muls(sigma_s_spectral, den);
+            f3    sigma_null_den = sub3(mk3(sigma_t_prime, sigma_t_prime, sigma_t_prime), sigma_t_den);
+            float Ps = fabsf(sigma_t_den.x * throughput.x) + fabsf(sigma_t_den.y * throughput.y) +
+                       fabsf(sigma_t_den.z * throughput.z);
+            float Pn = fabsf(sigma_null_den.x * throughput.x) + fabsf(sigma_null_den.y * throughput.y) +
+                       fabsf(sigma_null_den.z * throughput.z);
+            float c = (Ps + Pn);
+            float e = rng_next(&rng) * c;
+            if (e < Ps)
+            {
+                throughput = mul3(throughput, muls(sigma_s_den, inv_sigma * c / (Ps)));
+                ++num_scatters;
+                break;
+            }
+            else
+                throughput = mul3(throughput, muls(sigma_null_den, inv_sigma * c / Pn));
+        }
+        if (through)
+        {
+            cr_o = add3(cr_o, muls(cr_d, t_far)); /* :1809-1813 */
+            continue;
+        }
+        C->scatters++;
+
+        frame_t frame = make_frame(cr_d);
+        {
+            /* :1822-1851, num_scatters already incremented */
+            float s2 = hyperion_s(num_scatters - 5);
+            float reduction2 = (1.0f - s2) + s2 * (1.0f - P->g);
+            float density_prime2 = reduction2 * density;
+            float sigma_t_prime2 = max_sigma_t * density_prime2 * d_max;
+            float inv_sigma2     = 1.0f / sigma_t_prime2;
+            float ph = vpo_hg_eval(g, dot3(frame.n, sun_dir));
+            f3    a  = tr_spectral(S, boxMin, boxMax, pos, muls(sun_dir, 1e10f), inv_sigma2, density_prime2,
+                                   sigma_t_spectral, &rng, C);
+            radiance = add3(radiance, mul3(sun_power, mul3(muls(throughput, ph), a)));
+        }
+        float r0 = rng_next(&rng);
+        float r1 = rng_next(&rng);
+        f3 new_dir = normalize3(frame_to_world(&frame, hg_sample_local(g, r0, r1))); /* :1935-1937 */
+        cr_o = pos;
+        cr_d = new_dir;
+    }
+
+    radiance = muls(radiance, brightness);
+    out[0] = fmaxf(radiance.x, 0.0f);
+    out[1] = fmaxf(radiance.y, 0.0f);
+    out[2] = fmaxf(radiance.z, 0.0f);
+    out[3] = (float)((double)i * 0.001); /* :1942 */
+}
+
 /* ------------------------------------------------------- A2: __d_render -- */
 /* kernel.cu:1285-1591: global majorant (volume max assumed 1), no restarts */
 static void sample_global(const vpo_scene* S, const vpo_param* P, uint32_t x, uint32_t y, int spp, float out[4],
@@ -841,6 +954,7 @@ void vpo_render_sample(const vpo_scene* S, const vpo_param* P, int x, int y, int
     vpo_counters local;
     memset(&local, 0, sizeof local);
     if (S->estimator == VPO_EST_DECOMP) sample_decomp(S, P, (uint32_t)x, (uint32_t)y, frame, out, &local);
+    else if (S->estimator == VPO_EST_BOUNDED) sample_bounded(S, P, (uint32_t)x, (uint32_t)y, frame, out, &local);
     else sample_global(S, P, (uint32_t)x, (uint32_t)y, frame, out, &local);
     local.samples = 1;
     if (C)

@@ -34,7 +34,8 @@ typedef struct
 } vpo_param;
 
 enum { VPO_RNG_SAMPLERH = 0, VPO_RNG_PHILOX = 1 };
-enum { VPO_EST_GLOBAL = 0 /* __d_render, kernel.cu:1285 */, VPO_EST_DECOMP = 1 /* __d_render_bounded_decomp, :1958 */ };
+enum { VPO_EST_GLOBAL = 0 /* __d_render, kernel.cu:1285 */, VPO_EST_DECOMP = 1 /* __d_render_bounded_decomp, :1958 */,
+       VPO_EST_BOUNDED = 2 /* __d_render_bounded, :1667 */ };
 
 typedef struct
 {

@@ -10,6 +10,9 @@ __global__ __launch_bounds__(256) void rate_k(unsigned long long* out, float see
 {
     float    a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     unsigned u0 = threadIdx.x * 2654435761u + 1u, u1 = u0 + 17u, u2 = u0 + 31u, u3 = u0 + 51u, u4 = u0 + 71u, u5 = u0 + 91u, u6 = u0 + 111u, u7 = u0 + 131u;
+    double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;
+    if (OP == 49) asm volatile("s_mov_b64 vcc, 0x5555" ::: "vcc");
+    if (OP == 36) asm volatile("s_mov_b64 s[10:11], 0x5555" ::: "s10", "s11");
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; i++)
     {
@@ -47,8 +50,28 @@ __global__ __launch_bounds__(256) void rate_k(unsigned long long* out, float see
         if (OP == 29) { R8F(asm volatile("v_fmac_f32 %0, %0, %0" : "+v"(x));) }
         if (OP == 30) { R8F(asm volatile("v_exp_f32 %0, %0" : "+v"(x));) }
         if (OP == 31) { R8F(asm volatile("v_rndne_f32 %0, %0" : "+v"(x));) }
+#define R8D(stmt) { double& x = d0; stmt } { double& x = d1; stmt } { double& x = d2; stmt } { double& x = d3; stmt } { double& x = d4; stmt } { double& x = d5; stmt } { double& x = d6; stmt } { double& x = d7; stmt }
+        if (OP == 32) { R8D(asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 33) { R8D(asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 34) { R8D(asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(x));) }
+        if (OP == 35) { R8D(asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(x) : "v"(u0) : "vcc");) }
+        if (OP == 36) { R8F(asm volatile("v_cndmask_b32_e64 %0, %0, %0, s[10:11]" : "+v"(x) :: "s10", "s11");) }
+        if (OP == 37) { R8D(asm volatile("v_lshl_add_u64 %0, %0, 3, %0" : "+v"(x));) }
+        if (OP == 38) { R8F(asm volatile("v_cmp_lt_f32_e64 s[10:11], %0, %0" :: "v"(x) : "s10", "s11");) }
+        if (OP == 39) { R8U(asm volatile("v_add_u32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 40) { R8U(asm volatile("v_and_b32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 41) { R8F(asm volatile("v_fmaak_f32 %0, %0, %0, 0x3e2aaaab" : "+v"(x));) }
+        if (OP == 42) { R8F(asm volatile("v_cvt_f32_ubyte2 %0, %0" : "+v"(x));) }
+        if (OP == 43) { R8U(asm volatile("v_bitop3_b32 %0, %0, %0, %0 bitop3:0x96" : "+v"(x));) }
+        if (OP == 44) { R8U(asm volatile("v_xad_u32 %0, %0, %0, %0" : "+v"(x));) }
+        if (OP == 45) { R8F(asm volatile("v_mov_b32 %0, %0" : "+v"(x));) }
+        if (OP == 46) { R8U(asm volatile("v_lshl_or_b32 %0, %0, 3, %0" : "+v"(x));) }
+        if (OP == 47) { R8D(asm volatile("v_mul_f64 %0, %0, %0" : "+v"(x));) }
+        if (OP == 48) { R8F(asm volatile("v_med3_f32 %0, %0, %0, %0" : "+v"(x));) }
+        if (OP == 49) { R8F(asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(x));) }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    a0 += (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
     float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7);
     if (s == 123.456f) out[1] = 1;
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
@@ -72,7 +95,7 @@ int main()
 {
     unsigned long long* d;
     CHK(hipMalloc(&d, 16));
-    for (int w : {1, 2, 4})
+    for (int w : {1, 4, 8})
     {
 #define RUN(op, nm) run<op>(nm, d, w)
         RUN(0, "v_fma_f32"); RUN(12, "v_mul_f32"); RUN(21, "v_add_f32"); RUN(29, "v_fmac_f32"); RUN(13, "v_max_f32"); RUN(1, "v_mul_lo_u32"); RUN(26, "v_mul_hi_u32");
@@ -81,6 +104,9 @@ int main()
         RUN(27, "v_div_scale_f32"); RUN(28, "v_div_fmas_f32"); RUN(8, "v_div_fixup_f32"); RUN(9, "v_alignbit_b32"); RUN(10, "v_xor_b32"); RUN(22, "v_lshlrev_b32");
         RUN(11, "v_cndmask_b32"); RUN(15, "v_bfe_u32"); RUN(16, "v_max_i32"); RUN(17, "v_cmp_lt_f32"); RUN(23, "v_sub_u32_sdwa"); RUN(24, "v_frexp_mant_f32");
         RUN(25, "v_ldexp_f32");
+        RUN(32, "v_pk_add_f32"); RUN(33, "v_pk_mul_f32"); RUN(34, "v_pk_fma_f32"); RUN(35, "v_mad_u64_u32"); RUN(36, "v_cndmask_e64_sgpr"); RUN(37, "v_lshl_add_u64");
+        RUN(38, "v_cmp_lt_f32_e64"); RUN(39, "v_add_u32"); RUN(40, "v_and_b32"); RUN(41, "v_fmaak_f32"); RUN(42, "v_cvt_f32_ubyte2"); RUN(43, "v_bitop3_b32");
+        RUN(44, "v_xad_u32"); RUN(45, "v_mov_b32"); RUN(46, "v_lshl_or_b32"); RUN(47, "v_mul_f64"); RUN(48, "v_med3_f32"); RUN(49, "v_cndmask_vcc_set");
     }
     return 0;
 }

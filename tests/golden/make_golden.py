@@ -82,7 +82,7 @@ def oracle_renders():
     grid = O.julia(32)
     env = scenes.synthetic_env()
     out = {"julia32": grid}
-    for est, name in ((O.EST_DECOMP, "decomp"), (O.EST_GLOBAL, "global")):
+    for est, name in ((O.EST_DECOMP, "decomp"), (O.EST_GLOBAL, "global"), (O.EST_BOUNDED, "bounded")):
         for rng, rname in ((O.RNG_SAMPLERH, "samplerh"), (O.RNG_PHILOX, "philox")):
             sc = O.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, estimator=est,
                                rng_mode=rng, seed=(123, 456))

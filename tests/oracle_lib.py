@@ -13,7 +13,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 _LIB = None
 
 RNG_SAMPLERH, RNG_PHILOX = 0, 1
-EST_GLOBAL, EST_DECOMP = 0, 1
+EST_GLOBAL, EST_DECOMP, EST_BOUNDED = 0, 1, 2
 
 
 class Param(C.Structure):

@@ -73,7 +73,7 @@ def test_bounds_against_brute_force(oracle, brick):
 def test_golden_renders_regression(oracle):
     grid = GOLD["julia32"]
     env = scenes.synthetic_env()
-    for est, name in ((oracle.EST_DECOMP, "decomp"), (oracle.EST_GLOBAL, "global")):
+    for est, name in ((oracle.EST_DECOMP, "decomp"), (oracle.EST_GLOBAL, "global"), (oracle.EST_BOUNDED, "bounded")):
         for rng, rname in ((oracle.RNG_SAMPLERH, "samplerh"), (oracle.RNG_PHILOX, "philox")):
             sc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, estimator=est,
                                     rng_mode=rng, seed=(123, 456))
@@ -116,7 +116,7 @@ def test_white_furnace(oracle):
     g = oracle.julia(32)
     env = np.zeros((8, 16, 4), np.float32)
     env[..., :3] = 0.5
-    for est in (oracle.EST_DECOMP, oracle.EST_GLOBAL):
+    for est in (oracle.EST_DECOMP, oracle.EST_GLOBAL, oracle.EST_BOUNDED):
         sc = oracle.OracleScene(g, env, scenes.DEFAULT_SUN_DIR, (0.0, 0.0, 0.0), estimator=est)
         P = oracle.default_param(48, 36)
         acc = None
@@ -132,7 +132,7 @@ def test_majorant_invariance(oracle):
     g = oracle.julia(32)
     env = scenes.synthetic_env()
     imgs = []
-    for est in (oracle.EST_DECOMP, oracle.EST_GLOBAL):
+    for est in (oracle.EST_DECOMP, oracle.EST_GLOBAL, oracle.EST_BOUNDED):
         sc = oracle.OracleScene(g, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, estimator=est,
                                 rng_mode=oracle.RNG_PHILOX, seed=(5, est))
         P = oracle.default_param(32, 24, density=40.0)
@@ -141,6 +141,7 @@ def test_majorant_invariance(oracle):
             acc, _ = sc.render_frame(P, f, acc)
         imgs.append(acc[..., :3].mean(axis=(0, 1)) / 10)
     assert np.allclose(imgs[0], imgs[1], rtol=0.08)
+    assert np.allclose(imgs[0], imgs[2], rtol=0.08)
 
 
 def test_math_accuracy(oracle):

@@ -44,7 +44,7 @@ def _oracle_frames(osc, oP, frames):
     return acc, tot
 
 
-@pytest.mark.parametrize("est", [1, 0])
+@pytest.mark.parametrize("est", [1, 0, 2])
 @pytest.mark.parametrize("rng_mode", [0, 1])
 def test_julia32_frames_bit_exact(vp, oracle, est, rng_mode):
     grid = oracle.julia(32)
@@ -140,7 +140,7 @@ def test_against_committed_golden_vectors(vp, oracle):
     grid = vp.julia_volume(32)
     assert np.array_equal(grid, gold["julia32"])
     env = scenes.synthetic_env()
-    for est, name in ((1, "decomp"), (0, "global")):
+    for est, name in ((1, "decomp"), (0, "global"), (2, "bounded")):
         for rng, rname in ((0, "samplerh"), (1, "philox")):
             vp.init_volume(grid, brick=1, linear=True)
             vp.init_envmap(env)
@@ -247,7 +247,8 @@ def test_gpu_bound_table_builder(vp, oracle, quantized, brick):
 
 @pytest.mark.parametrize("case", ["ragged_image", "one_pixel", "tiny_volume", "isotropic_absorbing", "zero_density",
                                   "negative_g", "late_frames_philox", "off_centre_box", "global_chromatic",
-                                  "global_chromatic_philox", "global_point_filter"])
+                                  "global_chromatic_philox", "global_point_filter", "bounded_chromatic_philox",
+                                  "bounded_segment_cap", "decomp_scatter_cap"])
 def test_edge_cases_bit_exact(vp, oracle, case):
     global W, H
     W0, H0 = W, H
@@ -275,6 +276,17 @@ def test_edge_cases_bit_exact(vp, oracle, case):
             frames = range(5)
         elif case == "global_point_filter":
             est, linear = 0, False
+        elif case == "bounded_chromatic_philox":
+            est, rng = 2, 1
+            kw = dict(g=0.5, albedo=(0.95, 0.8, 0.6), sigma_t=(1.0, 0.7, 0.45), density=120.0)
+            frames = range(11, 14)  # past frame 10: __d_render_bounded still never reads the opacity volume
+        elif case in ("bounded_segment_cap", "decomp_scatter_cap"):
+            # a solid, dense, non-absorbing block: paths run into max_depth = 800 (kernel.cu:34)
+            est = 2 if case.startswith("bounded") else 1
+            grid = np.full((16, 16, 16), 255, np.uint8)
+            kw = dict(density=4000.0, g=0.0)
+            W, H = 24, 16
+            frames = range(1)
         elif case == "off_centre_box":
             box = ((-0.3, -1.1, 0.2), (1.2, 0.4, 1.9))
             env = np.full((1, 1, 4), 0.25, np.float32)   # 1x1 environment
@@ -295,6 +307,10 @@ def test_edge_cases_bit_exact(vp, oracle, case):
         got = buf.download()
         buf.free()
         assert np.array_equal(got, ref, equal_nan=True), f"{case}: max abs diff {np.nanmax(np.abs(got - ref))}"
+        if case == "bounded_segment_cap":
+            assert ref[..., 3].max() == np.float32(0.8)   # heat = 800 * 0.001 for a capped sample
+        if case == "decomp_scatter_cap":
+            assert ref[..., 3].max() == 800.0
     finally:
         W, H = W0, H0
 
