@@ -92,24 +92,25 @@ struct RngSamplerH
         return result;
     }
     __device__ __forceinline__ float next() { return u2f(0x3f800000u | (word() >> 9)) - 1.0f; }
-    __device__ __forceinline__ void prepare2() {}
+    // the reference's stream is sequential: the pair tags of the counter-based generator mean nothing here
+    __device__ __forceinline__ float next_a() { return next(); }
+    __device__ __forceinline__ float next_b() { return next(); }
 };
 
-// Philox2x32-10 (Salmon et al., SC'11).  Draw n of sample (x, y, frame) is word n&1 of
-// philox2x32_10(counter = (n>>1, x<<16|y), key = (frame ^ k0) + k1).  Pairs are generated at ONE place per
-// tracking step (prepare2), so the ten multiply rounds run once per step for the whole wave instead of
-// wherever a lane happens to run dry.
+// Philox2x32-10 (Salmon et al., SC'11), numbered in PAIRS of draws: next_a() computes
+// philox2x32_10(counter = (pair index, x<<16|y), key = (frame ^ k0) + k1) and returns word 0, next_b() returns
+// word 1 of the same block.  The integrator draws (free flight, collision test) and the two phase-function
+// variates as such pairs, so the ten multiply rounds sit at one place per tracking step, for the whole wave,
+// with no buffer bookkeeping; a pair whose second word is not needed just drops it.
 struct RngPhilox
 {
     unsigned pix, key, pair;  // next pair index to generate
-    unsigned b0, b1, b2;      // queue of generated, not yet consumed words
-    int      have;
+    unsigned w1;              // second word of the current pair
     __device__ __forceinline__ void init(unsigned px, unsigned py, unsigned frame, unsigned key0, unsigned key1)
     {
-        pix = (px << 16) | py; key = (frame ^ key0) + key1; pair = 0; have = 0;
-        b0 = b1 = b2 = 0;
+        pix = (px << 16) | py; key = (frame ^ key0) + key1; pair = 0; w1 = 0;
     }
-    __device__ __forceinline__ void gen(unsigned& o0, unsigned& o1)
+    __device__ __forceinline__ float next_a()
     {
         unsigned c0 = pair, c1 = pix, k = key;
 #pragma unroll
@@ -121,30 +122,11 @@ struct RngPhilox
             c0 = n0;
             k += 0x9E3779B9u;
         }
-        o0 = c0; o1 = c1;
+        w1 = c1;
         pair++;
+        return u2f(0x3f800000u | (c0 >> 9)) - 1.0f;
     }
-    // make sure the next two draws are buffered
-    __device__ __forceinline__ void prepare2()
-    {
-        if (have < 2)
-        {
-            unsigned n0, n1;
-            gen(n0, n1);
-            if (have == 0) { b0 = n0; b1 = n1; }
-            else { b1 = n0; b2 = n1; }
-            have += 2;
-        }
-    }
-    __device__ __forceinline__ unsigned word()
-    {
-        if (have == 0) { gen(b0, b1); have = 2; }
-        unsigned r = b0;
-        b0 = b1; b1 = b2;
-        have--;
-        return r;
-    }
-    __device__ __forceinline__ float next() { return u2f(0x3f800000u | (word() >> 9)) - 1.0f; }
+    __device__ __forceinline__ float next_b() { return u2f(0x3f800000u | (w1 >> 9)) - 1.0f; }
 };
 
 // ------------------------------------------------------------------ texture fetches
@@ -161,14 +143,14 @@ __device__ __forceinline__ f3 to_local(const SceneDev& S, f3 pos)
 __device__ __forceinline__ void axis_linear(float pn, int n, int& i, float& fw)
 {
     float xb = fma_(pn, (float)n, -0.5f);  // the unit's own scaling: one rounding
+    // below the first texel centre both taps clamp to texel 0: the same as sitting exactly on it (i = 0, w = 0)
+    xb       = __builtin_fmaxf(xb, 0.0f);
     float fl = __builtin_floorf(xb);
     float fr = xb - fl;
     i        = (int)fl;
     fw       = __builtin_floorf(fma_(fr, 256.0f, 0.5f)) * (1.0f / 256.0f);  // round-to-nearest of fr*256, /256
-    // the packed cell of voxel i already holds the clamped (i, i+1) pair; i < 0 degenerates to texel 0
-    fw = i < 0 ? 0.0f : fw;
-    i  = i < 0 ? 0 : i;
-    i  = i > n - 1 ? n - 1 : i;
+    // the packed cell of voxel i already holds the clamped (i, i+1) pair
+    i = i > n - 1 ? n - 1 : i;
 }
 __device__ __forceinline__ int axis_point(float pn, int n)
 {

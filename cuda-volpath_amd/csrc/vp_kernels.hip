@@ -155,8 +155,8 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
         {
             rad = rad + sun_power * (((ACH ? f3{thr.x, thr.x, thr.x} : thr) * ph) * nee_a);
             Frame fr(pd);
-            float r0 = rng.next();
-            float r1 = rng.next();
+            float r0 = rng.next_a();
+            float r1 = rng.next_b();
             rd       = normalize(fr.to_world(hg_sample_local(phase_g, r0, r1)));
             if (LOCAL) inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
             st       = ST_SETUP;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
                     {
                         // analog decomposition tracking kernel.cu:2048-2054 (quirk Q7)
                         sigma_c       = min_sig * cur_density * d_min;
-                        distc         = dist - logf_(rng.next()) / fmaxf(sigma_c, 1e-20f);
+                        distc         = dist - logf_(rng.next_a()) / fmaxf(sigma_c, 1e-20f);
                         float sigma_r = fmaxf(sigma_t_prime - sigma_c, 1e-20f);
                         inv_sigma     = 1.0f / sigma_r;
                     }
@@ -348,8 +348,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
             if (st == ST_TRACK || st == ST_SHADOW)
             {
                 const bool shadow = st == ST_SHADOW;
-                rng.prepare2();                          // both draws of this step come from buffered words
-                dist += -logf_(rng.next()) * inv_sigma;  // kernel.cu:2085 / :784
+                dist += -logf_(rng.next_a()) * inv_sigma;  // kernel.cu:2085 / :784
                 if (dist >= t_end || (shadow && terms == 7))
                 {
                     if (shadow)
@@ -380,7 +379,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
                 {
                     f3    p   = ro + rd * dist;
                     float den = sample_density01<QUANT>(S, p) * cur_density;  // vol_sigma_t kernel.cu:682-695
-                    float e   = rng.next();
+                    float e   = rng.next_b();
                     if (COUNT) c_den++;
                     if (shadow)
                     {
@@ -672,7 +671,7 @@ __global__ void test_rng_k(unsigned x, unsigned y, unsigned frame, unsigned k0, 
     if (threadIdx.x || blockIdx.x) return;
     RNG r;
     r.init(x, y, frame, k0, k1);
-    for (int i = 0; i < n; i++) out[i] = r.next();
+    for (int i = 0; i < n; i++) out[i] = (i & 1) ? r.next_b() : r.next_a();
 }
 template <bool QUANT>
 __global__ void test_density_k(SceneDev S, const float* pos, float* out, int n)

@@ -83,7 +83,7 @@ typedef struct
     uint32_t sx, sy;         /* sampler.h state */
     uint32_t ctr[2], key;    /* philox: ctr = (draw pair index, x<<16|y), key = (frame ^ seed0) + seed1 */
     uint32_t buf[2];
-    uint32_t n; /* draws so far */
+    uint32_t n; /* philox: pairs so far */
     uint64_t* draws;
 } rng_t;
 
@@ -118,26 +118,32 @@ static void rng_init(rng_t* r, const vpo_scene* S, uint32_t px, uint32_t py, uin
     }
 }
 
-/* sampler.h:25-29: float in [0,1) from the top 23 bits */
-static inline float rng_next(rng_t* r)
+/* sampler.h:25-29: float in [0,1) from the top 23 bits.
+ *
+ * The integrator's draws come in natural pairs -- (free-flight distance, collision test) and the two
+ * Henyey-Greenstein variates -- so the counter-based mode numbers PAIRS: the first draw of a pair (`second` = 0)
+ * computes philox2x32_10(counter = (pair index, x<<16|y), key) and returns word 0, the second returns word 1 of
+ * the same block.  A first draw that follows a first draw (a tracking step that left its segment before the
+ * collision test, or the lone control-distance draw of kernel.cu:2052) simply drops the unused word.
+ * sampler.h mode is the reference's sequential stream and ignores the tag. */
+static inline float rng_draw(rng_t* r, int second)
 {
     uint32_t w;
     if (r->mode == VPO_RNG_SAMPLERH)
         w = samplerh_next(&r->sx, &r->sy);
-    else
+    else if (!second)
     {
-        /* draw n is word n&1 of the pair with index n>>1 */
-        if ((r->n & 1u) == 0)
-        {
-            r->ctr[0] = r->n >> 1;
-            vpo_philox2x32_10(r->ctr, r->key, r->buf);
-        }
-        w = r->buf[r->n & 1u];
+        r->ctr[0] = r->n++;
+        vpo_philox2x32_10(r->ctr, r->key, r->buf);
+        w = r->buf[0];
     }
-    r->n++;
+    else
+        w = r->buf[1];
     if (r->draws) (*r->draws)++;
     return vpo_u2f(0x3f800000u | (w >> 9)) - 1.0f;
 }
+#define rng_next_a(r) rng_draw((r), 0)
+#define rng_next_b(r) rng_draw((r), 1)
 
 void vpo_rng_stream(int mode, uint32_t x, uint32_t y, uint32_t frame, uint32_t k0, uint32_t k1, int n, float* out)
 {
@@ -146,7 +152,7 @@ void vpo_rng_stream(int mode, uint32_t x, uint32_t y, uint32_t frame, uint32_t k
     S.rng_mode = mode; S.seed[0] = k0; S.seed[1] = k1;
     rng_t r;
     rng_init(&r, &S, x, y, frame, NULL);
-    for (int i = 0; i < n; i++) out[i] = rng_next(&r);
+    for (int i = 0; i < n; i++) out[i] = rng_draw(&r, i & 1);
 }
 
 /* ------------------------------------------------------- Julia voxeliser -- */
@@ -547,10 +553,10 @@ static f3 tr_spectral(const vpo_scene* S, f3 bmin, f3 bmax, f3 start, f3 end, fl
     int   xterm = 0, yterm = 0, zterm = 0;
     for (;;)
     {
-        dist += -vpo_logf(rng_next(rng)) * inv_sigma;
+        dist += -vpo_logf(rng_next_a(rng)) * inv_sigma;
         if (dist >= max_t || (xterm && yterm && zterm)) break;
         f3    pos = add3(o, muls(d, dist));
-        float e   = rng_next(rng);
+        float e   = rng_next_b(rng);
         float den = vol_sigma_t(S, pos, density, C);
         if (!xterm && e < sigma_t_spectral.x * den * inv_sigma) xterm = 1;
         if (!yterm && e < sigma_t_spectral.y * den * inv_sigma) yterm = 1;
@@ -641,7 +647,7 @@ static void sample_decomp(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
         if (use_decomposition)
         {
             sigma_c_prime    = min_sigma_t * density_prime * d_min;
-            distc            = dist - vpo_logf(rng_next(&rng)) / fmaxf(sigma_c_prime, 1e-20f);
+            distc            = dist - vpo_logf(rng_next_a(&rng)) / fmaxf(sigma_c_prime, 1e-20f);
             sigma_r_prime    = fmaxf(sigma_t_prime - sigma_c_prime, 1e-20f);
             sigma_c_spectral = mk3(sigma_c_prime, sigma_c_prime, sigma_c_prime);
         }
@@ -659,7 +665,7 @@ static void sample_decomp(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
         int through;
         for (;;)
         {
-            dist += -vpo_logf(rng_next(&rng)) * inv_sigma;
+            dist += -vpo_logf(rng_next_a(&rng)) * inv_sigma;
             if (dist >= distc || dist >= t_far)
             {
                 pos = add3(cr_o, muls(cr_d, distc));
@@ -678,7 +684,7 @@ static void sample_decomp(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
             float Pn = fabsf(sigma_null_den.x * throughput.x) + fabsf(sigma_null_den.y * throughput.y) +
                        fabsf(sigma_null_den.z * throughput.z);
             float c = (Ps + Pn);
-            float e = rng_next(&rng) * c;
+            float e = rng_next_b(&rng) * c;
             if (e < Ps)
             {
                 throughput = mul3(throughput, muls(sigma_s_den, inv_sigma_t * c / (Ps)));
@@ -721,8 +727,8 @@ static void sample_decomp(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
             radiance = add3(radiance, mul3(sun_power, mul3(muls(throughput, ph), a)));
         }
 
-        float r0 = rng_next(&rng);
-        float r1 = rng_next(&rng);
+        float r0 = rng_next_a(&rng);
+        float r1 = rng_next_b(&rng);
         f3 new_dir = normalize3(frame_to_world(&frame, hg_sample_local(phase_g, r0, r1)));
         cr_o = pos;
         cr_d = new_dir;
@@ -787,7 +793,7 @@ static void sample_bounded(const vpo_scene* S, const vpo_param* P, uint32_t x, u
         int through = 0;
         for (;;)
         {
-            dist += -vpo_logf(rng_next(&rng)) * inv_sigma; /* :1757 */
+            dist += -vpo_logf(rng_next_a(&rng)) * inv_sigma; /* :1757 */
             pos = add3(cr_o, muls(cr_d, dist));
             if (dist >= t_far)
             {
@@ -804,7 +810,7 @@ static void sample_bounded(const vpo_scene* S, const vpo_param* P, uint32_t x, u
             float Pn = fabsf(sigma_null_den.x * throughput.x) + fabsf(sigma_null_den.y * throughput.y) +
                        fabsf(sigma_null_den.z * throughput.z);
             float c = (Ps + Pn);
-            float e = rng_next(&rng) * c;
+            float e = rng_next_b(&rng) * c;
             if (e < Ps)
             {
                 throughput = mul3(throughput, muls(sigma_s_den, inv_sigma * c / (Ps)));
@@ -834,8 +840,8 @@ static void sample_bounded(const vpo_scene* S, const vpo_param* P, uint32_t x, u
                                    sigma_t_spectral, &rng, C);
             radiance = add3(radiance, mul3(sun_power, mul3(muls(throughput, ph), a)));
         }
-        float r0 = rng_next(&rng);
-        float r1 = rng_next(&rng);
+        float r0 = rng_next_a(&rng);
+        float r1 = rng_next_b(&rng);
         f3 new_dir = normalize3(frame_to_world(&frame, hg_sample_local(g, r0, r1))); /* :1935-1937 */
         cr_o = pos;
         cr_d = new_dir;
@@ -894,7 +900,7 @@ static void sample_global(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
         int through = 0;
         for (;;)
         {
-            dist += -vpo_logf(rng_next(&rng)) * inv_sigma;
+            dist += -vpo_logf(rng_next_a(&rng)) * inv_sigma;
             pos = add3(cr_o, muls(cr_d, dist));
             if (dist >= t_far) { through = 1; break; }
 
@@ -908,7 +914,7 @@ static void sample_global(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
             float Pn = fabsf(sigma_null_den.x * throughput.x) + fabsf(sigma_null_den.y * throughput.y) +
                        fabsf(sigma_null_den.z * throughput.z);
             float c = (Pa + Ps + Pn);
-            float e = rng_next(&rng) * c;
+            float e = rng_next_b(&rng) * c;
             if (e < Pa + Ps)
             {
                 throughput = mul3(throughput, muls(sigma_s_den, inv_sigma * c / (Pa + Ps)));
@@ -935,8 +941,8 @@ static void sample_global(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
             float ph = vpo_hg_eval(g, dot3(frame.n, sun_dir));
             radiance = add3(radiance, mul3(sun_power, mul3(muls(throughput, ph), a)));
         }
-        float r0 = rng_next(&rng);
-        float r1 = rng_next(&rng);
+        float r0 = rng_next_a(&rng);
+        float r1 = rng_next_b(&rng);
         f3 new_dir = normalize3(frame_to_world(&frame, hg_sample_local(g, r0, r1)));
         cr_o = pos;
         cr_d = new_dir;
