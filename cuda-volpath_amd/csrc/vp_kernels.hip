@@ -282,17 +282,9 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
         if (__ballot(st != ST_DONE || !exhausted) == 0ull) break;  // queue drained and every lane idle
 
         // =========================================================== fast path: tracking
-#pragma unroll 1
-        for (int iter = 0;; iter++)
-        {
-            bool active = (st == ST_TRACK) || (st == ST_SHADOW) || (LOCAL && st == ST_SETUP);
-            unsigned long long am = __ballot(active);
-            unsigned long long wm = __ballot(!active && !(st == ST_DONE && exhausted));
-            unsigned nwait = (unsigned)__popcll(wm);
-            if (am == 0ull || nwait >= L.wait_lanes || (nwait > 0u && iter >= (int)L.wait_iters)) break;
-            if (COUNT && lane == 0) { d_iter++; d_act += (unsigned)__popcll(am); d_shadow += (unsigned)__popcll(__ballot(st == ST_SHADOW)); }
-            if (!active) continue;
-
+        // one segment set-up (local-majorant estimators) and one tracking step, as lambdas: the loop below runs
+        // them twice per pass so that the wave-level bookkeeping (ballots, wait policy) is paid once per two steps
+        auto segment_setup = [&]() __attribute__((always_inline)) {
             if (LOCAL && st == ST_SETUP)
             {
                 // intersectSuperVolume kernel.cu:1626-1661 (quirks Q6, Q10): the bound is fetched before the hit test
@@ -344,7 +336,8 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
                     st    = ST_TRACK;
                 }
             }
-
+        };
+        auto tracking_step = [&]() __attribute__((always_inline)) {
             if (st == ST_TRACK || st == ST_SHADOW)
             {
                 const bool shadow = st == ST_SHADOW;
@@ -442,6 +435,26 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
                     }
                 }
             }
+        };
+#pragma unroll 1
+        for (int iter = 0;; iter += 2)
+        {
+            bool active = (st == ST_TRACK) || (st == ST_SHADOW) || (LOCAL && st == ST_SETUP);
+            unsigned long long am = __ballot(active);
+            unsigned long long wm = __ballot(!active && !(st == ST_DONE && exhausted));
+            unsigned nwait = (unsigned)__popcll(wm);
+            if (am == 0ull || nwait >= L.wait_lanes || (nwait > 0u && iter >= (int)L.wait_iters)) break;
+            if (COUNT && lane == 0) { d_iter++; d_act += (unsigned)__popcll(am); d_shadow += (unsigned)__popcll(__ballot(st == ST_SHADOW)); }
+            if (!active) continue;
+            segment_setup();
+            tracking_step();
+            if (COUNT)
+            {
+                unsigned long long am2 = __ballot((st == ST_TRACK) || (st == ST_SHADOW) || (LOCAL && st == ST_SETUP));
+                if (lane == 0) { d_iter++; d_act += (unsigned)__popcll(am2); d_shadow += (unsigned)__popcll(__ballot(st == ST_SHADOW)); }
+            }
+            segment_setup();
+            tracking_step();
         }
     }
 

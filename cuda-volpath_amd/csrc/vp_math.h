@@ -17,13 +17,13 @@ __device__ __forceinline__ unsigned f2u(float f) { return __float_as_uint(f); }
 // natural logarithm on {0} U [2^-126, inf); log(0) = -inf
 __device__ __forceinline__ float logf_(float x)
 {
+    // mantissa folded into (sqrt(2)/2, sqrt(2)] without a select: adding 2^23 - 0x3504f4 to the bit pattern carries
+    // into the exponent field exactly when the mantissa field exceeds that of fl(sqrt 2) = 0x3fb504f3
     unsigned ix = f2u(x);
-    int      e  = (int)(ix >> 23) - 127;
-    float    m  = u2f((ix & 0x007fffffu) | 0x3f800000u);
-    bool     up = m > 1.41421356f;
-    m           = up ? m * 0.5f : m;
-    e           = up ? e + 1 : e;
-    float r     = m - 1.0f;
+    unsigned iy = ix + 0x004afb0cu;
+    int      e  = (int)(iy >> 23) - 127;
+    float    m  = u2f((iy & 0x007fffffu) + 0x3f3504f4u);
+    float    r  = m - 1.0f;
     float z     = r * r;
     float p     = 7.0376836292E-2f;
     p           = fma_(p, r, -1.1514610310E-1f);

@@ -69,6 +69,26 @@ __global__ __launch_bounds__(256) void rate_k(unsigned long long* out, float see
         if (OP == 47) { R8D(asm volatile("v_mul_f64 %0, %0, %0" : "+v"(x));) }
         if (OP == 48) { R8F(asm volatile("v_med3_f32 %0, %0, %0, %0" : "+v"(x));) }
         if (OP == 49) { R8F(asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(x));) }
+        if (OP == 50) { R8F(asm volatile("v_cmp_lt_f32 vcc, %0, %0\n v_cndmask_b32 %0, %0, %0, vcc" : "+v"(x) :: "vcc");) }
+        if (OP == 51) { R8F(asm volatile("v_cndmask_b32_e64 %0, %0, %0, vcc" : "+v"(x));) }
+        if (OP == 52) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a0)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a1)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a2));
+                        asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a3)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a4)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a5));
+                        asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a6)); asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(a7)); }
+        if (OP == 53) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a0)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a1)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a2));
+                        asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a3)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a4)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a5));
+                        asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a6), "v"(a5) : "vcc"); asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(a7)); }
+        if (OP == 54) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a0)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a1)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a2));
+                        asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a3)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a4)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a5));
+                        asm volatile("v_cmp_lt_f32_e64 s[10:11], %0, %1" :: "v"(a6), "v"(a5) : "s10", "s11"); asm volatile("s_nop 1\n v_cndmask_b32_e64 %0, %0, %0, s[10:11]" : "+v"(a7)); }
+        if (OP == 55) { R8U(asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x) :: "vcc");) }
+        if (OP == 56) { R8U(asm volatile("v_bfi_b32 %0, %0, %0, %0" : "+v"(x));) }
+        if (OP == 57) { R8U(asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(x));) }
+        if (OP == 58) { R8F(asm volatile("v_mul_f32 %0, 0x3f8ccccd, %0" : "+v"(x));) }
+        if (OP == 59) { R8F(asm volatile("v_mul_f32_e64 %0, %0, %0" : "+v"(x));) }
+        if (OP == 60) { R8F(asm volatile("v_add_f32_e64 %0, %0, %0" : "+v"(x));) }
+        if (OP == 61) { R8F(asm volatile("v_sub_f32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 62) { R8F(asm volatile("v_min_f32 %0, %0, %0" : "+v"(x));) }
+        if (OP == 63) { R8F(asm volatile("s_nop 0" ::: );) }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     a0 += (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
@@ -79,23 +99,30 @@ __global__ __launch_bounds__(256) void rate_k(unsigned long long* out, float see
 template <int OP>
 int run(const char* name, unsigned long long* d, int waves_per_simd)
 {
-    const int iters = 2000;
+    const int iters = 10000;
     // one CU-filling launch: blocks of 256 threads (4 waves = 1 per SIMD) x waves_per_simd per CU x 256 CUs
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(rate_k<OP>, dim3(256 * waves_per_simd), dim3(256), 0, 0, d, 1.5f, iters);  // warm
+    CHK(hipEventRecord(e0, 0));
     hipLaunchKernelGGL(rate_k<OP>, dim3(256 * waves_per_simd), dim3(256), 0, 0, d, 1.5f, iters);
+    CHK(hipEventRecord(e1, 0));
     CHK(hipDeviceSynchronize());
+    float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long h[2];
     CHK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
     // memtime ticks at 100 MHz on gfx9 (constant clock); convert with the shader clock estimate below
     double ticks = (double)h[0];
-    printf("%-22s waves/SIMD %d: %8.0f ticks for %d x 8 inst/wave -> %.3f ticks per wave-inst per SIMD\n", name, waves_per_simd, ticks, iters,
-           ticks / (iters * 8.0 * waves_per_simd));
+    // wall: the whole launch issues iters*8 instructions per wave, waves_per_simd waves on each SIMD
+    printf("%-22s waves/SIMD %d: %8.0f ticks for %d x 8 inst/wave -> %.3f ticks per wave-inst per SIMD | launch %.1f us -> %.3f ns per wave-inst per SIMD\n", name, waves_per_simd, ticks, iters,
+           ticks / (iters * 8.0 * waves_per_simd), ms * 1e3, ms * 1e6 / (iters * 8.0 * waves_per_simd));
     return 0;
 }
 int main()
 {
     unsigned long long* d;
     CHK(hipMalloc(&d, 16));
-    for (int w : {1, 4, 8})
+    for (int w : {1, 5, 8})
     {
 #define RUN(op, nm) run<op>(nm, d, w)
         RUN(0, "v_fma_f32"); RUN(12, "v_mul_f32"); RUN(21, "v_add_f32"); RUN(29, "v_fmac_f32"); RUN(13, "v_max_f32"); RUN(1, "v_mul_lo_u32"); RUN(26, "v_mul_hi_u32");
@@ -107,6 +134,8 @@ int main()
         RUN(32, "v_pk_add_f32"); RUN(33, "v_pk_mul_f32"); RUN(34, "v_pk_fma_f32"); RUN(35, "v_mad_u64_u32"); RUN(36, "v_cndmask_e64_sgpr"); RUN(37, "v_lshl_add_u64");
         RUN(38, "v_cmp_lt_f32_e64"); RUN(39, "v_add_u32"); RUN(40, "v_and_b32"); RUN(41, "v_fmaak_f32"); RUN(42, "v_cvt_f32_ubyte2"); RUN(43, "v_bitop3_b32");
         RUN(44, "v_xad_u32"); RUN(45, "v_mov_b32"); RUN(46, "v_lshl_or_b32"); RUN(47, "v_mul_f64"); RUN(48, "v_med3_f32"); RUN(49, "v_cndmask_vcc_set");
+        RUN(50, "cmp+cndmask_vcc(x2)"); RUN(51, "v_cndmask_e64_vcc"); RUN(52, "7fma+cndmask_vcc"); RUN(53, "6fma+cmp+cnd_vcc"); RUN(54, "6fma+cmp+cnd_sgpr"); RUN(55, "v_addc_co_u32");
+        RUN(56, "v_bfi_b32"); RUN(57, "v_ashrrev_i32"); RUN(58, "v_mul_f32_lit"); RUN(59, "v_mul_f32_e64"); RUN(60, "v_add_f32_e64"); RUN(61, "v_sub_f32"); RUN(62, "v_min_f32"); RUN(63, "s_nop");
     }
     return 0;
 }
