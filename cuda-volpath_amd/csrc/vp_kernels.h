@@ -5,7 +5,12 @@
 #include "vp_device.h"
 
 #define VP_BLOCK 256
+#ifndef VP_BLOCK_LDS
 #define VP_BLOCK_LDS 512              // workgroup size of the LDS-bound-table variant
+#endif
+#ifndef VP_MIN_WAVES
+#define VP_MIN_WAVES 1                // launch-bounds hint: waves per SIMD the register budget must allow
+#endif
 #define VP_LDS_BOUND_ENTRIES 32768     // (max,min) byte pairs staged in LDS: 64 KiB
 #define VP_CHUNK 256  // samples a wave takes from the global queue per atomic
 // the inner tracking loop of a wave runs until this many lanes are parked on an event, or until
@@ -15,6 +20,10 @@
 #endif
 #ifndef VP_WAIT_ITERS
 #define VP_WAIT_ITERS 16
+#endif
+// tracking steps per pass of the inner loop: the wave-level bookkeeping (ballots, wait policy) is paid once per pass
+#ifndef VP_STEPS_PER_PASS
+#define VP_STEPS_PER_PASS 4
 #endif
 
 namespace vp

@@ -41,7 +41,7 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
 // bitwise identical (same operations on the same values), so one is carried and the collision sums are
 // formed from one product, (m + m) + m, exactly as the three-channel expression evaluates.
 template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH>
-__global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(SceneDev S, LaunchDev L)
+__global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
     if (LDSB)
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
 
     unsigned long long c_den = 0, c_bnd = 0, c_opa = 0, c_env = 0, c_sca = 0, c_smp = 0;
     unsigned long long d_iter = 0, d_act = 0, d_outer = 0, d_shadow = 0;  // debug (lane 0 counts wave events)
+    unsigned long long t_slow = 0, t_fast = 0, t_mark = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;  // shader cycles
 
     const unsigned lane = threadIdx.x & 63u;
     unsigned chunk_next = 0, chunk_end = 0;  // wave-uniform
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
             if (__ballot(st == ST_DONE && !exhausted) == 0ull) break;
         }
         if (__ballot(st != ST_DONE || !exhausted) == 0ull) break;  // queue drained and every lane idle
+        if (COUNT) { unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) t_slow += t - t_mark; t_mark = t; }
 
         // =========================================================== fast path: tracking
         // one segment set-up (local-majorant estimators) and one tracking step, as lambdas: the loop below runs
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
             }
         };
 #pragma unroll 1
-        for (int iter = 0;; iter += 2)
+        for (int iter = 0;; iter += VP_STEPS_PER_PASS)
         {
             bool active = (st == ST_TRACK) || (st == ST_SHADOW) || (LOCAL && st == ST_SETUP);
             unsigned long long am = __ballot(active);
@@ -448,22 +450,27 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK) void render_k(Scene
             if (!active) continue;
             segment_setup();
             tracking_step();
-            if (COUNT)
+#pragma unroll
+            for (int u = 1; u < VP_STEPS_PER_PASS; u++)
             {
-                unsigned long long am2 = __ballot((st == ST_TRACK) || (st == ST_SHADOW) || (LOCAL && st == ST_SETUP));
-                if (lane == 0) { d_iter++; d_act += (unsigned)__popcll(am2); d_shadow += (unsigned)__popcll(__ballot(st == ST_SHADOW)); }
+                if (COUNT)
+                {
+                    unsigned long long am2 = __ballot((st == ST_TRACK) || (st == ST_SHADOW) || (LOCAL && st == ST_SETUP));
+                    if (lane == 0) { d_iter++; d_act += (unsigned)__popcll(am2); d_shadow += (unsigned)__popcll(__ballot(st == ST_SHADOW)); }
+                }
+                segment_setup();
+                tracking_step();
             }
-            segment_setup();
-            tracking_step();
         }
+        if (COUNT) { unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) t_fast += t - t_mark; t_mark = t; }
     }
 
     if (COUNT)
     {
         // wave reduction, one atomic per counter per wave
-        unsigned long long vals[10] = {c_smp, c_den, c_bnd, c_opa, c_env, c_sca, d_iter, d_act, d_outer, d_shadow};
+        unsigned long long vals[12] = {c_smp, c_den, c_bnd, c_opa, c_env, c_sca, d_iter, d_act, d_outer, d_shadow, t_slow, t_fast};
 #pragma unroll
-        for (int q = 0; q < 10; q++)
+        for (int q = 0; q < 12; q++)
         {
             unsigned long long v = vals[q];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
