@@ -45,6 +45,11 @@ struct State
     float*      d_opacity   = nullptr;
     float4*     d_env       = nullptr;
     int         env_w = 0, env_h = 0;
+    // active environment sampling (!PASSIVE_ENVMAP): CDF tables, built on demand
+    bool        env_mis     = false;
+    bool        env_tables  = false;  // tables match the current envmap
+    float*      d_env_cdf_x = nullptr;
+    float*      d_env_cdf_y = nullptr;
     bool        linear      = false;  // kernel.cu:351: point filtering until set_texture_filter_mode(true)
     int         brick_next  = 1;
     int         brick       = 1;
@@ -222,6 +227,8 @@ int do_opacity(const float* dir)
     return VP_OK;
 }
 
+int build_env_tables();
+
 int do_envmap(const vp_float4* data, int w, int h)
 {
     int rc = ensure_device();
@@ -238,6 +245,32 @@ int do_envmap(const vp_float4* data, int w, int h)
     HIPCHK(hipStreamSynchronize(G.stream));  // caller owns `data`
     G.S.env = G.d_env; G.S.env_w = w; G.S.env_h = h;
     G.have_env = true;
+    G.env_tables = false;
+    if (G.env_mis) return build_env_tables();
+    return VP_OK;
+}
+
+// init_envmap kernel.cu:1144-1210: luminance CDFs and HDRpdfnormAlt for the current environment
+int build_env_tables()
+{
+    if (G.env_tables || !G.have_env) return VP_OK;
+    const int w = G.env_w, h = G.env_h;
+    float *lum = nullptr, *rows = nullptr, *norm = nullptr;
+    if (G.d_env_cdf_x) HIPCHK(hipFree(G.d_env_cdf_x));
+    if (G.d_env_cdf_y) HIPCHK(hipFree(G.d_env_cdf_y));
+    HIPCHK(hipMalloc((void**)&G.d_env_cdf_x, (size_t)w * h * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&G.d_env_cdf_y, (size_t)h * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&lum, (size_t)w * h * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&rows, (size_t)h * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&norm, sizeof(float)));
+    launch_env_tables(G.d_env, w, h, lum, rows, G.d_env_cdf_x, G.d_env_cdf_y, norm, G.stream);
+    HIPCHK(hipGetLastError());
+    float hnorm = 0.0f;
+    HIPCHK(hipMemcpyAsync(&hnorm, norm, sizeof(float), hipMemcpyDeviceToHost, G.stream));
+    HIPCHK(hipStreamSynchronize(G.stream));
+    HIPCHK(hipFree(lum)); HIPCHK(hipFree(rows)); HIPCHK(hipFree(norm));
+    G.S.env_cdf_x = G.d_env_cdf_x; G.S.env_cdf_y = G.d_env_cdf_y; G.S.env_pdfnorm_alt = hnorm;
+    G.env_tables = true;
     return VP_OK;
 }
 
@@ -306,7 +339,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p)
             L.stage = nullptr;
         HIPCHK(hipMemsetAsync(G.d_queue, 0, sizeof(unsigned), G.stream));
         // the brick table goes through LDS when it fits (decomposition estimator, byte table <= 64 KiB)
-        const bool lds_bounds = G.use_lds_bounds && G.est == VP_EST_DECOMP && G.quant &&
+        const bool lds_bounds = G.use_lds_bounds && G.est == VP_EST_DECOMP && G.quant && !G.env_mis &&
                                 (size_t)S.bnx * S.bny * S.bnz <= (size_t)VP_LDS_BOUND_ENTRIES;
         const unsigned bsz = lds_bounds ? VP_BLOCK_LDS : VP_BLOCK;
         unsigned waves  = (L.total_items + 63) / 64;
@@ -315,7 +348,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p)
         if (blocks > cap) blocks = cap;
         hipEvent_t e0 = get_event(), e1 = get_event();
         HIPCHK(hipEventRecord(e0, G.stream));
-        launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, (int)blocks, G.stream);
+        launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, (int)blocks, G.stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, G.stream));
         G.events.emplace_back(e0, e1);
@@ -367,7 +400,10 @@ void free_envmap(void)
     if (!G.have_env) return;
     (void)hipStreamSynchronize(G.stream);
     (void)hipFree(G.d_env);
+    (void)hipFree(G.d_env_cdf_x);
+    (void)hipFree(G.d_env_cdf_y);
     G.d_env = nullptr; G.S.env = nullptr; G.env_w = G.env_h = 0; G.have_env = false;
+    G.d_env_cdf_x = G.d_env_cdf_y = nullptr; G.S.env_cdf_x = G.S.env_cdf_y = nullptr; G.env_tables = false;
 }
 
 void set_sun(float* sun_dir, float* sun_power)
@@ -454,6 +490,26 @@ int vp_set_rng(int mode, uint32_t k0, uint32_t k1)
 {
     if (mode != VP_RNG_SAMPLERH && mode != VP_RNG_PHILOX) return fail(VP_E_ARG, "unknown rng %d", mode);
     G.rng = mode; G.key0 = k0; G.key1 = k1;
+    return VP_OK;
+}
+int vp_set_envmap_sampling(int mode)
+{
+    if (mode != VP_ENV_PASSIVE && mode != VP_ENV_MIS) return fail(VP_E_ARG, "unknown environment sampling mode %d", mode);
+    int rc = ensure_device();
+    if (rc) return rc;
+    G.env_mis = mode == VP_ENV_MIS;
+    if (G.env_mis) return build_env_tables();
+    return VP_OK;
+}
+int vp_get_env_tables(float* cdf_y, float* cdf_x, float* pdfnorm_alt)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!G.env_tables) return fail(VP_E_STATE, "no environment tables: vp_set_envmap_sampling(VP_ENV_MIS) and init_envmap first");
+    HIPCHK(hipStreamSynchronize(G.stream));
+    if (cdf_y) HIPCHK(hipMemcpy(cdf_y, G.d_env_cdf_y, (size_t)G.env_h * sizeof(float), hipMemcpyDeviceToHost));
+    if (cdf_x) HIPCHK(hipMemcpy(cdf_x, G.d_env_cdf_x, (size_t)G.env_w * G.env_h * sizeof(float), hipMemcpyDeviceToHost));
+    if (pdfnorm_alt) *pdfnorm_alt = G.S.env_pdfnorm_alt;
     return VP_OK;
 }
 int vp_set_bound_brick(int brick)

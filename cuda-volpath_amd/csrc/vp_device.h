@@ -16,6 +16,7 @@ __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y +
 __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
 __device__ __forceinline__ f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return f3{a.x / s, a.y / s, a.z / s}; }  // helper_math.h:997-1000
 __device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ f3 cross(f3 a, f3 b)
 {
@@ -31,6 +32,8 @@ constexpr float kPi     = VP_PI_F;
 constexpr float kPi2    = VP_PI_F / 2.0f;
 constexpr float k1Pi    = 1.0f / VP_PI_F;
 constexpr float k1TwoPi = 1.0f / (VP_PI_F * 2.0f);
+constexpr float kTwoPi  = VP_PI_F * 2.0f;
+constexpr float k1TwoPiPi = 1.0f / VP_PI_F / (VP_PI_F * 2.0f);  // vecmath.h:16
 
 // Param of the reference (src/param.h:4-12); 44 bytes
 struct ParamDev
@@ -59,6 +62,10 @@ struct SceneDev
     float sun_cos;   // 94 / sqrt(94^2 + 0.45^2), kernel.cu:1263
     float cam[12];   // row-major 3x4 camera-to-world, kernel.cu:626
     float cam_z;     // -1 / tan(54.43 * 0.00872664626), kernel.cu:1985
+    // active environment sampling (!PASSIVE_ENVMAP): luminance CDFs (kernel.cu:1144-1210) and HDRpdfnormAlt
+    const float* env_cdf_y;  // env_h
+    const float* env_cdf_x;  // env_w * env_h
+    float        env_pdfnorm_alt;
 };
 
 // ------------------------------------------------------------------------------ RNG
@@ -290,6 +297,48 @@ __device__ __forceinline__ f3 eval_envmap(const SceneDev& S, f3 dir)
     int    j = axis_point(v, S.env_h);
     float4 t = S.env[(size_t)i + (size_t)S.env_w * (size_t)j];
     return f3{t.x, t.y, t.z};
+}
+
+// luminance kernel.cu:945-953: the literals are double, so is the arithmetic
+__device__ __forceinline__ float luminance(f3 c)
+{
+    return (float)((double)c.x * 0.2126 + (double)c.y * 0.7152 + (double)c.z * 0.0722);
+}
+// sample_y / sample_x kernel.cu:904-943: lower-bound binary search on a point-sampled CDF
+__device__ __forceinline__ int cdf_search(const float* cdf, int n, float r)
+{
+    int begin = 0, end = n - 1;
+    while (end > begin)
+    {
+        int   mid = begin + (end - begin) / 2;
+        float c   = cdf[mid];
+        if (c >= r) end = mid;
+        else begin = mid + 1;
+    }
+    return begin;
+}
+// sample_envmap kernel.cu:979-1006 (MULT_PDF 0, PRE_WARP 1): returns the pdf, (u,v) become texel-centre coordinates
+__device__ __forceinline__ float sample_envmap(const SceneDev& S, float& u, float& v, f3& c)
+{
+    int iy = cdf_search(S.env_cdf_y, S.env_h, v);
+    int ix = cdf_search(S.env_cdf_x + (size_t)iy * (size_t)S.env_w, S.env_w, u);
+    u = ((float)ix + 0.5f) / (float)S.env_w;
+    v = ((float)iy + 0.5f) / (float)S.env_h;
+    int    i = axis_point(u, S.env_w);
+    int    j = axis_point(v, S.env_h);
+    float4 t = S.env[(size_t)i + (size_t)S.env_w * (size_t)j];
+    c        = f3{t.x, t.y, t.z};
+    return luminance(c) * S.env_pdfnorm_alt;
+}
+// uv_to_dir kernel.cu:897-902
+__device__ __forceinline__ f3 uv_to_dir(float u, float v)
+{
+    float theta = u * kTwoPi;
+    float phi   = v * kPi;
+    float st, ct, sp, cp;
+    sincosf_(theta, st, ct);
+    sincosf_(phi, sp, cp);
+    return f3{sp * st, cp, sp * -ct};
 }
 
 // intersectBox kernel.cu:654-680 (quirk Q13)

@@ -26,7 +26,9 @@ enum : int
     EV_SCATTER = 4,  // collision found: direct-lighting set-up
     EV_NEE     = 5,  // shadow transmittance known: add sun light, sample the phase function
     EV_BG      = 6,  // ray left the medium: environment lookup
-    EV_WRITE   = 7   // path finished: emit the sample
+    EV_WRITE   = 7,  // path finished: emit the sample
+    EV_MIS     = 8,  // active environment sampling only: draw the one-sample-MIS direction, start its shadow ray
+    EV_HG      = 9   // sample the phase function, continue the path
 };
 
 __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
@@ -40,7 +42,9 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
 // ACH: achromatic medium (sigma_t and albedo equal in all three channels): the three throughput channels stay
 // bitwise identical (same operations on the same values), so one is carried and the collision sums are
 // formed from one product, (m + m) + m, exactly as the three-channel expression evaluates.
-template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH>
+// MIS: active environment sampling with one-sample MIS after the sun estimate (the reference's !PASSIVE_ENVMAP
+// build, kernel.cu:2220-2297); the shipped configuration is passive (MIS = false).
+template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool MIS>
 __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
@@ -81,6 +85,11 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void 
     float    cur_density = 0, d_max = 0, phase_g = 0, ph = 0;
     f3       nee_a = {};
     int      terms = 0;
+    // MIS only: colour and weight of the light estimate in flight, rad += nee_c * (nee_t * transmittance);
+    // 0 = sun, 1 = environment; the shadow majorant of this collision; the ray origin before the collision
+    f3       nee_c = {}, nee_t = {}, seg_o = {};
+    int      nee_stage = 0;
+    float    sh_inv_sigma = 0, sh_density = 0;
 
     unsigned long long c_den = 0, c_bnd = 0, c_opa = 0, c_env = 0, c_sca = 0, c_smp = 0;
     unsigned long long d_iter = 0, d_act = 0, d_outer = 0, d_shadow = 0;  // debug (lane 0 counts wave events)
@@ -94,6 +103,36 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void 
     {
         if (COUNT && lane == 0) d_outer++;
         // =========================================================== slow path: events
+        // Tr_spectral set-up kernel.cu:763-780: shadow ray from the collision point ro toward `end`
+        auto start_shadow = [&](f3 end, float inv_s, float den) __attribute__((always_inline)) {
+            f3    sd = normalize(end - ro);
+            float tn, tf;
+            bool  hitv = intersect_box(ro, sd, S, tn, tf);
+            if (!hitv)
+            {
+                nee_a = f3{1.0f, 1.0f, 1.0f};
+                st    = EV_NEE;
+            }
+            else
+            {
+                if (tn < 0.0f) tn = 0.0f;
+                f3 se       = ro - end;
+                t_end       = fminf(tf, __builtin_sqrtf(dot(se, se)));
+                dist        = tn;
+                terms       = 0;
+                rd          = sd;
+                inv_sigma   = inv_s;
+                cur_density = den;
+                st          = ST_SHADOW;
+            }
+        };
+        // the path goes on with a new segment; loop bounds kernel.cu:34 with :2015 / :1332 / :1716
+        auto next_segment = [&]() __attribute__((always_inline)) {
+            st = ST_SETUP;
+            if (EST == EST_GLOBAL) nsc++;
+            if (EST == EST_BOUNDED) seg++;
+            if ((EST == EST_BOUNDED ? seg : nsc) >= 800) st = EV_WRITE;
+        };
         // ---- collision: direct lighting set-up (kernel.cu:2161-2217 / :1458-1491)
         if (st == EV_SCATTER)
         {
@@ -115,6 +154,14 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void 
             }
             ph = hg_eval(phase_g, dot(rd, sun_dir));
             pd = rd;
+            if (MIS)
+            {
+                sh_inv_sigma = 1.0f / stp2;
+                sh_density   = dp2;
+                nee_stage    = 0;
+                nee_c        = sun_power;
+                nee_t        = (ACH ? f3{thr.x, thr.x, thr.x} : thr) * ph;
+            }
             // here ro already holds the collision point (set by the tracking step)
             if (EST == EST_DECOMP && frame > 10 && nsc > 20)
             {
@@ -126,45 +173,83 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void 
                 st     = EV_NEE;
             }
             else
+                start_shadow(sun_dir * 1e10f, 1.0f / stp2, dp2);
+        }
+#pragma unroll
+        for (int pass = 0; pass < (MIS ? 2 : 1); pass++)
+        {
+            // ---- a light estimate is complete (kernel.cu:2188-2189,:2209-2210 and :2254,:2290)
+            if (st == EV_NEE)
             {
-                // Tr_spectral set-up kernel.cu:763-780
-                f3    end = sun_dir * 1e10f;
-                f3    sd  = normalize(end - ro);
-                float tn, tf;
-                bool  hitv = intersect_box(ro, sd, S, tn, tf);
-                if (!hitv)
+                if (MIS)
                 {
-                    nee_a = f3{1.0f, 1.0f, 1.0f};
-                    st    = EV_NEE;
+                    rad = rad + nee_c * (nee_t * nee_a);
+                    st  = nee_stage == 0 ? EV_MIS : EV_HG;
                 }
                 else
                 {
-                    if (tn < 0.0f) tn = 0.0f;
-                    f3 se       = ro - end;
-                    t_end       = fminf(tf, __builtin_sqrtf(dot(se, se)));
-                    dist        = tn;
-                    terms       = 0;
-                    rd          = sd;
-                    inv_sigma   = 1.0f / stp2;
-                    cur_density = dp2;
-                    st          = ST_SHADOW;
+                    rad = rad + sun_power * (((ACH ? f3{thr.x, thr.x, thr.x} : thr) * ph) * nee_a);
+                    st  = EV_HG;
+                }
+            }
+            // ---- one-sample MIS of the environment (kernel.cu:2220-2297; same block at :1494-1560 and :1855-1932)
+            if (MIS && st == EV_MIS)
+            {
+                const float P_phase = 0.5f, P_envmap = 1.0f - P_phase;
+                const f3    thr3    = ACH ? f3{thr.x, thr.x, thr.x} : thr;
+                Frame       fr(pd);
+                nee_stage = 1;
+                if (rng.next_a() < P_phase)
+                {
+                    float u        = rng.next_a();
+                    float v        = rng.next_b();
+                    f3    brdf_dir = fr.to_world(hg_sample_local(phase_g, u, v));
+                    f3    envc     = eval_envmap(S, brdf_dir);
+                    if (COUNT) c_env++;
+                    float pdf_brdf        = hg_eval(phase_g, dot(fr.n, brdf_dir));
+                    float pdf_env_virtual = luminance(envc) * S.env_pdfnorm_alt;  // pdf_envmap :1009-1034
+                    float wa = pdf_brdf * P_phase, wb = pdf_env_virtual * P_envmap;
+                    float weight = wa / (wa + wb) / P_phase;
+                    nee_c = envc;
+                    nee_t = thr3 * weight;
+                    start_shadow(brdf_dir * 1e10f, sh_inv_sigma, sh_density);
+                }
+                else
+                {
+                    float u = rng.next_a();
+                    float v = rng.next_b();
+                    f3    envc;
+                    float pdf_env = sample_envmap(S, u, v, envc);
+                    if (COUNT) c_env++;
+                    if (pdf_env <= 0.0f)
+                    {
+                        // the reference `continue`s here (:2266): no scattered direction, the OLD ray goes on
+                        ro = seg_o;
+                        rd = pd;
+                        next_segment();
+                    }
+                    else
+                    {
+                        f3    envmap_dir       = uv_to_dir(u, v);
+                        float pdf_brdf_virtual = hg_eval(phase_g, dot(fr.n, envmap_dir));
+                        float wa = pdf_env * P_envmap, wb = pdf_brdf_virtual * P_phase;
+                        float weight = wa / (wa + wb) / P_envmap;
+                        nee_c = envc;
+                        nee_t = ((thr3 * pdf_brdf_virtual) / pdf_env) * weight;
+                        start_shadow(envmap_dir * 1e10f, sh_inv_sigma, sh_density);
+                    }
                 }
             }
         }
-        // ---- sun contribution + phase-function sampling (kernel.cu:2188-2189,:2209-2210,:2301-2303)
-        if (st == EV_NEE)
+        // ---- phase-function sampling (kernel.cu:2301-2303)
+        if (st == EV_HG)
         {
-            rad = rad + sun_power * (((ACH ? f3{thr.x, thr.x, thr.x} : thr) * ph) * nee_a);
             Frame fr(pd);
             float r0 = rng.next_a();
             float r1 = rng.next_b();
             rd       = normalize(fr.to_world(hg_sample_local(phase_g, r0, r1)));
             if (LOCAL) inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
-            st       = ST_SETUP;
-            if (EST == EST_GLOBAL) nsc++;
-            if (EST == EST_BOUNDED) seg++;
-            // max_depth kernel.cu:34, loop conditions :2015 / :1332 / :1716
-            if ((EST == EST_BOUNDED ? seg : nsc) >= 800) st = EV_WRITE;
+            next_segment();
         }
 #pragma unroll 1
         for (int rep = 0; rep < 4; rep++)
@@ -256,11 +341,15 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void 
             // ---- ray left the medium: background() kernel.cu:1258-1267 (quirk Q11)
             if (st == EV_BG)
             {
-                f3 bg;
-                if (nsc == 0 && dot(rd, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
-                else { bg = eval_envmap(S, rd); if (COUNT) c_env++; }
-                rad = rad + bg * (ACH ? f3{thr.x, thr.x, thr.x} : thr);
-                st  = EV_WRITE;
+                // with active environment sampling only unscattered paths see it directly (kernel.cu:2026-2030, :1340-1344)
+                if (!MIS || nsc == 0)
+                {
+                    f3 bg;
+                    if (nsc == 0 && dot(rd, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
+                    else { bg = eval_envmap(S, rd); if (COUNT) c_env++; }
+                    rad = rad + bg * (ACH ? f3{thr.x, thr.x, thr.x} : thr);
+                }
+                st = EV_WRITE;
             }
             // ---- path end: emit the sample (kernel.cu:2306-2316 / :1579-1589)
             if (st == EV_WRITE)
@@ -363,6 +452,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void 
                         }
                         else
                         {
+                            if (MIS) seg_o = ro;
                             ro = ro + rd * distc;  // control collision kernel.cu:2088
                             st = EV_SCATTER;
                         }
@@ -404,6 +494,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void 
                         thr.x      = thr.x * ((real ? a_s : a_n) * f);
                         if (real)
                         {
+                            if (MIS) seg_o = ro;
                             ro = p;
                             st = EV_SCATTER;
                         }
@@ -431,6 +522,7 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void 
                         thr        = thr * (sel * f);
                         if (real)
                         {
+                            if (MIS) seg_o = ro;
                             ro = p;
                             st = EV_SCATTER;
                         }
@@ -702,29 +794,36 @@ __global__ void test_density_k(SceneDev S, const float* pos, float* out, int n)
 }
 
 // ------------------------------------------------------------------ host-side launchers
-template <int EST, class RNG, bool LDSB, bool ACH>
-static void launch_render4(const SceneDev& S, const LaunchDev& L, bool quant, bool count, int blocks, hipStream_t st)
+template <int EST, class RNG, bool LDSB, bool ACH, bool MIS>
+static void launch_render5(const SceneDev& S, const LaunchDev& L, bool quant, bool count, int blocks, hipStream_t st)
 {
     const dim3 blk(LDSB ? VP_BLOCK_LDS : VP_BLOCK);
     if (quant)
     {
-        if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB, ACH>), dim3(blocks), blk, 0, st, S, L);
-        else hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB, ACH>), dim3(blocks), blk, 0, st, S, L);
+        if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB, ACH, MIS>), dim3(blocks), blk, 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB, ACH, MIS>), dim3(blocks), blk, 0, st, S, L);
     }
     else
     {
-        if (count) hipLaunchKernelGGL((render_k<EST, RNG, false, true, false, ACH>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
-        else hipLaunchKernelGGL((render_k<EST, RNG, false, false, false, ACH>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+        if (count) hipLaunchKernelGGL((render_k<EST, RNG, false, true, false, ACH, MIS>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, false, false, false, ACH, MIS>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
     }
 }
 template <int EST, class RNG, bool LDSB>
-static void launch_render3(const SceneDev& S, const LaunchDev& L, bool quant, bool count, bool ach, int blocks, hipStream_t st)
+static void launch_render3(const SceneDev& S, const LaunchDev& L, bool quant, bool count, bool ach, bool mis, int blocks, hipStream_t st)
 {
-    if (ach) launch_render4<EST, RNG, LDSB, true>(S, L, quant, count, blocks, st);
-    else launch_render4<EST, RNG, LDSB, false>(S, L, quant, count, blocks, st);
+    if (mis)
+    {
+        // active environment sampling: the rarely used build, kept off the LDS specialisation
+        if (ach) launch_render5<EST, RNG, false, true, true>(S, L, quant, count, blocks, st);
+        else launch_render5<EST, RNG, false, false, true>(S, L, quant, count, blocks, st);
+    }
+    else if (ach) launch_render5<EST, RNG, LDSB, true, false>(S, L, quant, count, blocks, st);
+    else launch_render5<EST, RNG, LDSB, false, false>(S, L, quant, count, blocks, st);
 }
 
-void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, int blocks, hipStream_t st)
+void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int blocks,
+                   hipStream_t st)
 {
     // achromatic medium: identical extinction and albedo in the three channels (e.g. preset #13, host.cpp:1308)
     const ParamDev& P = L.P;
@@ -732,28 +831,79 @@ void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool
                      P.albedo[1] == P.albedo[2];
     if (est == EST_DECOMP)
     {
-        if (lds_bounds && quant)
+        if (lds_bounds && quant && !mis)
         {
-            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, true>(S, L, quant, count, ach, blocks, st);
-            else launch_render3<EST_DECOMP, RngSamplerH, true>(S, L, quant, count, ach, blocks, st);
+            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, true>(S, L, quant, count, ach, mis, blocks, st);
+            else launch_render3<EST_DECOMP, RngSamplerH, true>(S, L, quant, count, ach, mis, blocks, st);
         }
         else
         {
-            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, false>(S, L, quant, count, ach, blocks, st);
-            else launch_render3<EST_DECOMP, RngSamplerH, false>(S, L, quant, count, ach, blocks, st);
+            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, false>(S, L, quant, count, ach, mis, blocks, st);
+            else launch_render3<EST_DECOMP, RngSamplerH, false>(S, L, quant, count, ach, mis, blocks, st);
         }
     }
     else if (est == EST_BOUNDED)
     {
         // the dead reference variant: no LDS specialisation, it is there for completeness
-        if (rng == RNG_PHILOX) launch_render3<EST_BOUNDED, RngPhilox, false>(S, L, quant, count, ach, blocks, st);
-        else launch_render3<EST_BOUNDED, RngSamplerH, false>(S, L, quant, count, ach, blocks, st);
+        if (rng == RNG_PHILOX) launch_render3<EST_BOUNDED, RngPhilox, false>(S, L, quant, count, ach, mis, blocks, st);
+        else launch_render3<EST_BOUNDED, RngSamplerH, false>(S, L, quant, count, ach, mis, blocks, st);
     }
     else
     {
-        if (rng == RNG_PHILOX) launch_render3<EST_GLOBAL, RngPhilox, false>(S, L, quant, count, ach, blocks, st);
-        else launch_render3<EST_GLOBAL, RngSamplerH, false>(S, L, quant, count, ach, blocks, st);
+        if (rng == RNG_PHILOX) launch_render3<EST_GLOBAL, RngPhilox, false>(S, L, quant, count, ach, mis, blocks, st);
+        else launch_render3<EST_GLOBAL, RngSamplerH, false>(S, L, quant, count, ach, mis, blocks, st);
     }
+}
+
+// ------------------------------------------------------------------ environment CDF tables (init_envmap, kernel.cu:1144-1210)
+// luminance * sin(phi) per texel (PRE_WARP, :1153-1161)
+__global__ void env_lum_k(const float4* env, float* lum, int w, int h)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * h) return;
+    int    y   = i / w;
+    float  phi = kPi * ((float)y + 0.5f) / (float)h;
+    float  sp, cp;
+    sincosf_(phi, sp, cp);
+    float4 t = env[i];
+    lum[i]   = luminance(f3{t.x, t.y, t.z}) * sp;
+}
+// build_cdf_1d (:1036-1055) of one row per thread: sequential float sums, as the reference's host loop
+__global__ void env_row_cdf_k(const float* lum, float* cdf_x, float* row_sum, int w, int h)
+{
+    int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= h) return;
+    const float* f   = lum + (size_t)y * w;
+    float*       cdf = cdf_x + (size_t)y * w;
+    float        sum = 0.0f;
+    for (int i = 0; i < w; i++) sum += f[i];
+    float norm = 1.0f / sum;
+    float I    = 0.0f;
+    for (int i = 0; i < w; i++) { I += f[i] * norm; cdf[i] = I; }
+    cdf[w - 1] = 1.0f;
+    row_sum[y] = sum;
+}
+// the CDF of the row sums and HDRpdfnormAlt (:1163-1166); one thread, the sums are sequential by definition
+__global__ void env_col_cdf_k(const float* lum, const float* row_sum, float* cdf_y, float* pdfnorm_alt, int w, int h)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    float lumsum = 0.0f;
+    for (size_t i = 0, n = (size_t)w * h; i < n; i++) lumsum += lum[i];
+    *pdfnorm_alt = (float)w * (float)h * k1TwoPiPi / lumsum;
+    float sum = 0.0f;
+    for (int i = 0; i < h; i++) sum += row_sum[i];
+    float norm = 1.0f / sum;
+    float I    = 0.0f;
+    for (int i = 0; i < h; i++) { I += row_sum[i] * norm; cdf_y[i] = I; }
+    cdf_y[h - 1] = 1.0f;
+}
+void launch_env_tables(const float4* env, int w, int h, float* lum, float* row_sum, float* cdf_x, float* cdf_y, float* pdfnorm_alt,
+                       hipStream_t st)
+{
+    int n = w * h;
+    hipLaunchKernelGGL(env_lum_k, dim3((n + 255) / 256), dim3(256), 0, st, env, lum, w, h);
+    hipLaunchKernelGGL(env_row_cdf_k, dim3((h + 63) / 64), dim3(64), 0, st, lum, cdf_x, row_sum, w, h);
+    hipLaunchKernelGGL(env_col_cdf_k, dim3(1), dim3(64), 0, st, lum, row_sum, cdf_y, pdfnorm_alt, w, h);
 }
 void launch_reduce(const LaunchDev& L, hipStream_t st)
 {

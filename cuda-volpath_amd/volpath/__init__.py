@@ -15,13 +15,14 @@ LIB_PATH = os.environ.get("VOLPATH_LIB", os.path.join(os.path.dirname(_HERE), "l
 
 EST_GLOBAL, EST_DECOMP, EST_BOUNDED = 0, 1, 2
 RNG_SAMPLERH, RNG_PHILOX = 0, 1
+ENV_PASSIVE, ENV_MIS = 0, 1
 
 # every symbol include/volpath.h declares (tests check the library exports each one)
 PART1_SYMBOLS = ["init_cuda", "set_texture_filter_mode", "free_cuda_buffers", "precompute_opacity", "init_envmap",
                  "free_envmap", "set_sun", "copy_inv_view_matrix", "copy_inv_model_matrix", "init_rng", "free_rng",
                  "render_kernel", "scale", "gamma_correct"]
 PART2_SYMBOLS = ["vp_last_error", "vp_version", "vp_device_count", "vp_set_device", "vp_set_stream", "vp_synchronize",
-                 "vp_set_estimator", "vp_set_rng", "vp_set_bound_brick", "vp_set_shard", "vp_render_frames",
+                 "vp_set_estimator", "vp_set_rng", "vp_set_envmap_sampling", "vp_get_env_tables", "vp_set_bound_brick", "vp_set_shard", "vp_render_frames",
                  "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity",
                  "vp_julia_voxelize", "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_malloc", "vp_free", "vp_memset",
                  "vp_upload", "vp_download"]
@@ -77,6 +78,7 @@ def lib():
         L.vp_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.vp_set_stream.argtypes = [C.c_void_p]
         L.vp_set_rng.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+        L.vp_get_env_tables.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.vp_render_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Param)]
         L.vp_read_counters.argtypes = [C.POINTER(Counters), C.c_int]
         L.vp_render_time_ms.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]
@@ -231,6 +233,19 @@ def set_estimator(est):
 
 def set_rng(mode, key=(0, 0)):
     _chk(lib().vp_set_rng(mode, key[0], key[1]))
+
+
+def set_envmap_sampling(mode):
+    """ENV_PASSIVE (the reference's shipped build) or ENV_MIS (its !PASSIVE_ENVMAP alternative)"""
+    _chk(lib().vp_set_envmap_sampling(mode))
+
+
+def env_tables(width, height):
+    cdf_y = np.empty(height, np.float32)
+    cdf_x = np.empty((height, width), np.float32)
+    norm = C.c_float()
+    _chk(lib().vp_get_env_tables(_p(cdf_y), _p(cdf_x), C.byref(norm)))
+    return cdf_y, cdf_x, norm.value
 
 
 def set_shard(rank, world):

@@ -117,6 +117,14 @@ int  vp_synchronize(void);
 
 int vp_set_estimator(int est);                         /* default VP_EST_DECOMP */
 int vp_set_rng(int mode, uint32_t key0, uint32_t key1); /* default VP_RNG_SAMPLERH */
+/* Environment lighting.  VP_ENV_PASSIVE is the reference's shipped build (PASSIVE_ENVMAP 1, kernel.cu:21): escaping paths
+ * look the environment up.  VP_ENV_MIS is its compiled-out alternative: luminance CDFs built in init_envmap
+ * (kernel.cu:1144-1210) and one-sample MIS between phase-function and environment sampling after each collision
+ * (kernel.cu:2220-2297, MULT_PDF 0, PRE_WARP 1); only unscattered paths then see the environment directly. */
+enum { VP_ENV_PASSIVE = 0, VP_ENV_MIS = 1 };
+int vp_set_envmap_sampling(int mode);                  /* default VP_ENV_PASSIVE */
+/* test hook: the tables of the current environment: cdf_y[h], cdf_x[w*h] (row CDFs), HDRpdfnormAlt; any may be NULL */
+int vp_get_env_tables(float* cdf_y, float* cdf_x, float* pdfnorm_alt);
 /* brick edge (power of two, 1 = the reference's per-voxel table) used by the NEXT init_cuda */
 int vp_set_bound_brick(int brick);
 /* pixel-tile sharding: this process renders the 8x8 tiles t with t % world == rank */

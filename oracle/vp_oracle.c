@@ -31,6 +31,7 @@ static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z);
 static inline f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline f3 muls(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+static inline f3 divs(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); } /* helper_math.h:997-1000 */
 /* helper_math.h:1248-1251, :1420-1423, :1291-1294, :1309-1313 (host branch :62-65) */
 static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 static inline f3 cross3(f3 a, f3 b)
@@ -48,6 +49,7 @@ static const float VP_TWO_PI   = VP_PI * 2.0f;
 static const float VP_PI_2     = VP_PI / 2.0f;
 static const float VP_1_PI     = 1.0f / VP_PI;
 static const float VP_1_TWOPI  = 1.0f / (VP_PI * 2.0f);
+static const float VP_1_TWO_PI_PI = 1.0f / VP_PI / (VP_PI * 2.0f); /* vecmath.h:16 */
 
 /* ------------------------------------------------------------------ RNG -- */
 /* sampler.h:3-11 */
@@ -424,6 +426,97 @@ void vpo_eval_envmap(const vpo_scene* S, const float dir[3], float rgb[3])
     rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
 }
 
+static inline float vpo_sinf(float a) { float s_, c_; vpo_sincosf(a, &s_, &c_); return s_; }
+static inline float vpo_cosf(float a) { float s_, c_; vpo_sincosf(a, &s_, &c_); return c_; }
+
+/* ---- active environment sampling (compiled out in the shipped reference: PASSIVE_ENVMAP 1, kernel.cu:21) ---- */
+/* luminance kernel.cu:945-953: double arithmetic (the literals are double), result narrowed to float */
+static inline float luminance3(float r, float g, float b)
+{
+    return (float)((double)r * 0.2126 + (double)g * 0.7152 + (double)b * 0.0722);
+}
+
+/* init_envmap kernel.cu:1144-1168 + build_cdf_1d/2d :1036-1070, configuration MULT_PDF 0, PRE_WARP 1 (:855-856):
+ * row CDFs of luminance*sin(phi), CDF of the row sums, and HDRpdfnormAlt.  pdfX/pdfY are only read under MULT_PDF
+ * and are not produced.  All sums are sequential float sums in texel order, as in the reference. */
+void vpo_build_env_tables(const float* env, int width, int height, float* cdf_y, float* cdf_x, float* pdfnorm_alt)
+{
+    size_t total = (size_t)width * (size_t)height;
+    float* lum   = (float*)malloc(total * sizeof(float));
+    float* rows  = (float*)malloc((size_t)height * sizeof(float));
+    for (int y = 0; y < height; y++)
+    {
+        float phi = VP_PI * ((float)y + 0.5f) / (float)height; /* :1158 */
+        float sp  = vpo_sinf(phi);
+        for (int x = 0; x < width; x++)
+        {
+            const float* t = env + 4 * ((size_t)x + (size_t)width * (size_t)y);
+            lum[x + (size_t)y * width] = luminance3(t[0], t[1], t[2]) * sp;
+        }
+    }
+    float lumsum = 0.0f;
+    for (size_t i = 0; i < total; i++) lumsum += lum[i];
+    *pdfnorm_alt = (float)width * (float)height * VP_1_TWO_PI_PI / lumsum; /* :1166 */
+    for (int y = 0; y < height; y++)
+    {
+        const float* f   = lum + (size_t)y * width;
+        float*       cdf = cdf_x + (size_t)y * width;
+        float        sum = 0.0f;
+        for (int i = 0; i < width; i++) sum += f[i];
+        float norm = 1.0f / sum;
+        float I    = 0.0f;
+        for (int i = 0; i < width; i++) { I += f[i] * norm; cdf[i] = I; }
+        cdf[width - 1] = 1.0f;
+        rows[y]        = sum;
+    }
+    {
+        float sum = 0.0f;
+        for (int i = 0; i < height; i++) sum += rows[i];
+        float norm = 1.0f / sum;
+        float I    = 0.0f;
+        for (int i = 0; i < height; i++) { I += rows[i] * norm; cdf_y[i] = I; }
+        cdf_y[height - 1] = 1.0f;
+    }
+    free(lum); free(rows);
+}
+
+/* sample_y / sample_x kernel.cu:904-943: lower-bound binary search on a point-sampled CDF texture */
+static int cdf_search(const float* cdf, int n, float r)
+{
+    int begin = 0, end = n - 1;
+    while (end > begin)
+    {
+        int   mid = begin + (end - begin) / 2;
+        float c   = cdf[mid];
+        if (c >= r) end = mid;
+        else begin = mid + 1;
+    }
+    return begin;
+}
+
+/* sample_envmap kernel.cu:979-1006: returns the pdf; (u,v) become the texel-centre coordinates */
+static float sample_envmap(const vpo_scene* S, float* u, float* v, f3* c, vpo_counters* C)
+{
+    int iy = cdf_search(S->env_cdf_y, S->env_h, *v);
+    int ix = cdf_search(S->env_cdf_x + (size_t)iy * S->env_w, S->env_w, *u);
+    *u = ((float)ix + 0.5f) / (float)S->env_w;
+    *v = ((float)iy + 0.5f) / (float)S->env_h;
+    C->env_lookups++;
+    int          i = tex_axis_point(*u, S->env_w);
+    int          j = tex_axis_point(*v, S->env_h);
+    const float* t = S->env + 4 * ((size_t)i + (size_t)S->env_w * (size_t)j);
+    *c = mk3(t[0], t[1], t[2]);
+    return luminance3(c->x, c->y, c->z) * S->env_pdfnorm_alt; /* consistent with the sine warp, :998 */
+}
+
+/* uv_to_dir kernel.cu:897-902 */
+static f3 uv_to_dir(float u, float v)
+{
+    float theta = u * VP_TWO_PI;
+    float phi   = v * VP_PI;
+    return mk3(vpo_sinf(phi) * vpo_sinf(theta), vpo_cosf(phi), vpo_sinf(phi) * -vpo_cosf(theta));
+}
+
 /* background kernel.cu:1258-1267 (quirk Q11) */
 static f3 background(const vpo_scene* S, f3 dir, int depth, vpo_counters* C)
 {
@@ -565,6 +658,59 @@ static f3 tr_spectral(const vpo_scene* S, f3 bmin, f3 bmax, f3 start, f3 end, fl
     return mk3((float)(1 - xterm), (float)(1 - yterm), (float)(1 - zterm));
 }
 
+/* test hook: how often the zero-pdf `continue` of the MIS block was taken (it needs a draw of exactly 0) */
+static uint64_t g_mis_zero_pdf = 0;
+uint64_t vpo_debug_mis_zero_pdf(void) { return __atomic_load_n(&g_mis_zero_pdf, __ATOMIC_RELAXED); }
+
+/* ------------------------------------ one-sample MIS of the environment -- */
+/* kernel.cu:2220-2297 (A1), :1494-1560 (A2), :1855-1932 (A3): identical in the three kernels.  With probability
+ * 1/2 a direction is drawn from the phase function, else from the environment's luminance CDF; balance heuristic.
+ * Returns 1 for the reference's `continue` on a zero-pdf environment sample: the path then goes on WITHOUT the
+ * scattered-direction update, i.e. from the old ray origin in the old direction (with the scatter already counted). */
+static int mis_envmap(const vpo_scene* S, rng_t* rng, vpo_counters* C, const frame_t* frame, float g, f3 pos,
+                      f3 throughput, float inv_sigma, float density_prime, f3 sigma_t_spectral, f3 boxMin,
+                      f3 boxMax, f3* radiance)
+{
+    const float P_phase  = 0.5f;
+    const float P_envmap = 1.0f - P_phase;
+    if (rng_next_a(rng) < P_phase)
+    {
+        float u = rng_next_a(rng);
+        float v = rng_next_b(rng);
+        f3    brdf_dir = frame_to_world(frame, hg_sample_local(g, u, v));
+        f3    envc     = eval_envmap(S, brdf_dir, C);
+        float pdf_brdf = vpo_hg_eval(g, dot3(frame->n, brdf_dir));
+        float pdf_env_virtual = luminance3(envc.x, envc.y, envc.z) * S->env_pdfnorm_alt; /* pdf_envmap :1009-1034 */
+        float a_ = pdf_brdf * P_phase, b_ = pdf_env_virtual * P_envmap;
+        float weight = a_ / (a_ + b_) / P_phase;
+        f3 a = tr_spectral(S, boxMin, boxMax, pos, muls(brdf_dir, 1e10f), inv_sigma, density_prime, sigma_t_spectral,
+                           rng, C);
+        *radiance = add3(*radiance, mul3(envc, mul3(muls(throughput, weight), a)));
+    }
+    else
+    {
+        float u = rng_next_a(rng);
+        float v = rng_next_b(rng);
+        f3    envc;
+        float pdf_env = sample_envmap(S, &u, &v, &envc, C);
+        if (pdf_env <= 0.0f)
+        {
+            __atomic_fetch_add(&g_mis_zero_pdf, 1, __ATOMIC_RELAXED);
+            return 1;
+        }
+        f3    envmap_dir       = uv_to_dir(u, v);
+        float pdf_brdf_virtual = vpo_hg_eval(g, dot3(frame->n, envmap_dir));
+        float a_ = pdf_env * P_envmap, b_ = pdf_brdf_virtual * P_phase;
+        float weight = a_ / (a_ + b_) / P_envmap;
+        f3 a = tr_spectral(S, boxMin, boxMax, pos, muls(envmap_dir, 1e10f), inv_sigma, density_prime, sigma_t_spectral,
+                           rng, C);
+        float ph = vpo_hg_eval(g, dot3(frame->n, envmap_dir));
+        f3    t  = muls(divs(muls(throughput, ph), pdf_env), weight);
+        *radiance = add3(*radiance, mul3(envc, mul3(t, a)));
+    }
+    return 0;
+}
+
 /* ----------------------------------------------------------- camera (Q3) -- */
 /* kernel.cu:1977-1987 / :1304-1314 */
 static void camera_ray(const vpo_scene* S, const vpo_param* P, uint32_t x, uint32_t y, f3* o, f3* d)
@@ -632,7 +778,9 @@ static void sample_decomp(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
         int   use_decomposition = d_min > 0.0f;
         if (!hit)
         {
-            radiance = add3(radiance, mul3(background(S, cr_d, num_scatters, C), throughput));
+            /* PASSIVE_ENVMAP: every escaping path sees the environment; otherwise only unscattered ones (:2026-2030) */
+            if (!S->env_mis || 0 == num_scatters)
+                radiance = add3(radiance, mul3(background(S, cr_d, num_scatters, C), throughput));
             break;
         }
         f3    pos  = add3(cr_o, muls(cr_d, t_near));
@@ -725,6 +873,9 @@ static void sample_decomp(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
                                 sigma_t_spectral, &rng, C);
             /* sun_light_power * (throughput * phase * a) */
             radiance = add3(radiance, mul3(sun_power, mul3(muls(throughput, ph), a)));
+            if (S->env_mis && mis_envmap(S, &rng, C, &frame, phase_g, pos, throughput, inv_sigma2, density_prime2,
+                                         sigma_t_spectral, boxMin, boxMax, &radiance))
+                continue; /* :2266 */
         }
 
         float r0 = rng_next_a(&rng);
@@ -776,7 +927,8 @@ static void sample_bounded(const vpo_scene* S, const vpo_param* P, uint32_t x, u
         (void)d_min;
         if (!hit)
         {
-            radiance = add3(radiance, mul3(background(S, cr_d, num_scatters, C), throughput)); /* :1724-1731 */
+            if (!S->env_mis || 0 == num_scatters) /* :1724-1731 */
+                radiance = add3(radiance, mul3(background(S, cr_d, num_scatters, C), throughput));
             break;
         }
         f3    pos;
@@ -839,6 +991,9 @@ static void sample_bounded(const vpo_scene* S, const vpo_param* P, uint32_t x, u
             f3    a  = tr_spectral(S, boxMin, boxMax, pos, muls(sun_dir, 1e10f), inv_sigma2, density_prime2,
                                    sigma_t_spectral, &rng, C);
             radiance = add3(radiance, mul3(sun_power, mul3(muls(throughput, ph), a)));
+            if (S->env_mis && mis_envmap(S, &rng, C, &frame, g, pos, throughput, inv_sigma2, density_prime2,
+                                         sigma_t_spectral, boxMin, boxMax, &radiance))
+                continue; /* :1900; the loop index still advances */
         }
         float r0 = rng_next_a(&rng);
         float r1 = rng_next_b(&rng);
@@ -884,7 +1039,8 @@ static void sample_global(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
         int   hit = intersect_box(cr_o, cr_d, boxMin, boxMax, &t_near, &t_far);
         if (!hit)
         {
-            radiance = add3(radiance, mul3(background(S, cr_d, i, C), throughput));
+            if (!S->env_mis || 0 == i) /* :1340-1344 */
+                radiance = add3(radiance, mul3(background(S, cr_d, i, C), throughput));
             break;
         }
         if (t_near < 0.0f) t_near = 0.0f;
@@ -925,7 +1081,8 @@ static void sample_global(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
         }
         if (through)
         {
-            radiance = add3(radiance, mul3(background(S, cr_d, i, C), throughput));
+            if (!S->env_mis || 0 == i) /* :1446-1450 */
+                radiance = add3(radiance, mul3(background(S, cr_d, i, C), throughput));
             break;
         }
         C->scatters++;
@@ -940,6 +1097,9 @@ static void sample_global(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
                                sigma_t_spectral, &rng, C);
             float ph = vpo_hg_eval(g, dot3(frame.n, sun_dir));
             radiance = add3(radiance, mul3(sun_power, mul3(muls(throughput, ph), a)));
+            if (S->env_mis && mis_envmap(S, &rng, C, &frame, g, pos, throughput, inv_sigma2, density_prime2,
+                                         sigma_t_spectral, boxMin, boxMax, &radiance))
+                continue; /* :1539; the depth index still advances */
         }
         float r0 = rng_next_a(&rng);
         float r1 = rng_next_b(&rng);

@@ -63,6 +63,11 @@ typedef struct
     int      estimator;
     int      rng_mode;
     uint32_t seed[2]; /* Philox: key = (frame ^ seed[0]) + seed[1] */
+    /* active environment sampling + one-sample MIS (!PASSIVE_ENVMAP, kernel.cu:2220-2297); 0 = the shipped passive mode */
+    int          env_mis;
+    const float* env_cdf_y; /* env_h */
+    const float* env_cdf_x; /* env_w * env_h */
+    float        env_pdfnorm_alt;
 } vpo_scene;
 
 typedef struct
@@ -96,6 +101,8 @@ void     vpo_precompute_opacity(const vpo_scene* S, const float light_dir[3], fl
 float    vpo_sample_density(const vpo_scene* S, const float pos[3]);
 void     vpo_sample_bound(const vpo_scene* S, const float pos[3], float out_max_min[2]);
 float    vpo_sample_opacity(const vpo_scene* S, const float pos[3]);
+void     vpo_build_env_tables(const float* env, int width, int height, float* cdf_y, float* cdf_x, float* pdfnorm_alt);
+uint64_t vpo_debug_mis_zero_pdf(void); /* test hook: zero-pdf `continue`s taken so far (kernel.cu:2266) */
 void     vpo_eval_envmap(const vpo_scene* S, const float dir[3], float rgb[3]);
 void     vpo_hg_sample(float g, const float n[3], float u0, float u1, float out[3]);
 float    vpo_hg_eval(float g, float cos_theta);

@@ -32,7 +32,9 @@ class Scene(C.Structure):
                 ("env", C.c_void_p), ("env_w", C.c_int), ("env_h", C.c_int),
                 ("sun_dir", C.c_float * 3), ("sun_power", C.c_float * 3), ("sun_power_original", C.c_float * 3),
                 ("inv_view", C.c_float * 12),
-                ("estimator", C.c_int), ("rng_mode", C.c_int), ("seed", C.c_uint32 * 2)]
+                ("estimator", C.c_int), ("rng_mode", C.c_int), ("seed", C.c_uint32 * 2),
+                ("env_mis", C.c_int), ("env_cdf_y", C.c_void_p), ("env_cdf_x", C.c_void_p),
+                ("env_pdfnorm_alt", C.c_float)]
 
 
 class Counters(C.Structure):
@@ -63,6 +65,8 @@ def lib():
         L.vpo_sample_density.restype = C.c_float
         L.vpo_sample_opacity.restype = C.c_float
         L.vpo_mat.argtypes = [C.c_void_p] + [C.c_float] * 6
+        L.vpo_build_env_tables.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vpo_debug_mis_zero_pdf.restype = C.c_uint64
         L.vpo_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float]
         L.vpo_gamma_correct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float]
         _LIB = L
@@ -113,7 +117,8 @@ class OracleScene:
     """Keeps numpy buffers alive next to the C struct."""
 
     def __init__(self, grid, env, sun_dir, sun_power, box=None, brick=1, radius=None, linear=True,
-                 estimator=EST_DECOMP, rng_mode=RNG_SAMPLERH, seed=(0, 0), inv_view=None, extra_dilate=None):
+                 estimator=EST_DECOMP, rng_mode=RNG_SAMPLERH, seed=(0, 0), inv_view=None, extra_dilate=None,
+                 env_mis=False):
         L = lib()
         self.grid = np.ascontiguousarray(grid)
         nz, ny, nx = self.grid.shape
@@ -155,6 +160,19 @@ class OracleScene:
         S.seed[:] = seed
         self.S = S
         self.opacity = None
+        if env_mis:
+            self.enable_env_mis()
+
+    def enable_env_mis(self):
+        """!PASSIVE_ENVMAP: luminance CDF tables (kernel.cu:1144-1210) + one-sample MIS in the integrator"""
+        S = self.S
+        self.cdf_y = np.empty(S.env_h, np.float32)
+        self.cdf_x = np.empty((S.env_h, S.env_w), np.float32)
+        norm = C.c_float()
+        lib().vpo_build_env_tables(_p(self.env), S.env_w, S.env_h, _p(self.cdf_y), _p(self.cdf_x), C.byref(norm))
+        S.env_mis, S.env_cdf_y, S.env_cdf_x = 1, _p(self.cdf_y).value, _p(self.cdf_x).value
+        S.env_pdfnorm_alt = norm.value
+        self.pdfnorm_alt = norm.value
 
     def precompute_opacity(self, threads=0):
         S = self.S

@@ -144,6 +144,34 @@ def test_majorant_invariance(oracle):
     assert np.allclose(imgs[0], imgs[2], rtol=0.08)
 
 
+def test_env_tables_and_mis_estimate(oracle):
+    """!PASSIVE_ENVMAP: the luminance CDFs (kernel.cu:1144-1210) and one-sample MIS (:2220-2297) estimate the same image."""
+    g = oracle.julia(32)
+    env = scenes.synthetic_env()
+    sc = oracle.OracleScene(g, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, env_mis=True,
+                            rng_mode=oracle.RNG_PHILOX, seed=(3, 1))
+    h, w = env.shape[:2]
+    # tables against a float64 restatement
+    phi = np.pi * (np.arange(h) + 0.5) / h
+    lum = (env[..., 0].astype(np.float64) * 0.2126 + env[..., 1] * 0.7152 + env[..., 2] * 0.0722) * np.sin(phi)[:, None]
+    assert np.allclose(sc.cdf_x, np.cumsum(lum, 1) / lum.sum(1, keepdims=True), atol=2e-5)
+    assert np.allclose(sc.cdf_y, np.cumsum(lum.sum(1)) / lum.sum(), atol=2e-5)
+    assert np.all(sc.cdf_x[:, -1] == 1.0) and sc.cdf_y[-1] == 1.0
+    assert np.isclose(sc.pdfnorm_alt, w * h / (2 * np.pi * np.pi) / lum.sum(), rtol=1e-5)
+    # the two builds agree in the mean
+    P = oracle.default_param(32, 24, density=60.0)
+    imgs = []
+    for mis in (True, False):
+        s2 = sc if mis else oracle.OracleScene(g, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER,
+                                               rng_mode=oracle.RNG_PHILOX, seed=(3, 1))
+        acc = None
+        for f in range(10):
+            acc, c = s2.render_frame(P, f, acc)
+        imgs.append(acc[..., :3].mean(axis=(0, 1)) / 10)
+        assert (c.env_lookups > c.samples) == mis
+    assert np.allclose(imgs[0], imgs[1], rtol=0.05)
+
+
 def test_math_accuracy(oracle):
     rng = np.random.default_rng(1)
     u = rng.random(200000).astype(np.float32)

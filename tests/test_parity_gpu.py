@@ -315,6 +315,88 @@ def test_edge_cases_bit_exact(vp, oracle, case):
         W, H = W0, H0
 
 
+@pytest.mark.parametrize("est", [1, 0, 2])
+@pytest.mark.parametrize("rng_mode", [0, 1])
+def test_active_envmap_mis_bit_exact(vp, oracle, est, rng_mode):
+    """The reference's !PASSIVE_ENVMAP build: CDF tables (kernel.cu:1144-1210) and one-sample MIS (:2220-2297)."""
+    grid = oracle.julia(32)
+    env = scenes.synthetic_env()
+    env[3, 5, :3] = 0.0   # a black texel inside a row: a zero-probability entry of the row CDF
+    osc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, estimator=est, rng_mode=rng_mode,
+                             seed=(9, 4), env_mis=True)
+    kw = dict(density=150.0, g=0.6) if est != 1 else {}
+    preset = scenes.PRESET1 if est == 2 else None
+    oP, vP = oracle.default_param(W, H, **kw), vp.make_param(W, H, **kw)
+    if preset:
+        oracle.mat(oP, *preset)
+        vp.mat(vP, *preset)
+    try:
+        vp.set_envmap_sampling(vp.ENV_MIS)
+        vp.init_volume(grid, brick=1)
+        vp.init_envmap(env)
+        cdf_y, cdf_x, norm = vp.env_tables(env.shape[1], env.shape[0])
+        assert np.array_equal(cdf_y, osc.cdf_y) and np.array_equal(cdf_x, osc.cdf_x)
+        assert np.float32(norm) == np.float32(osc.pdfnorm_alt)
+        vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+        vp.set_camera()
+        vp.set_estimator(est)
+        vp.set_rng(rng_mode, (9, 4))
+        vp.set_shard(0, 1)
+        osc.precompute_opacity()
+        vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+        frames = range(8, 14)     # across the frame > 10 opacity switch of the live kernel
+        ref, cnt = _oracle_frames(osc, oP, frames)
+        buf = vp.DeviceBuffer(W, H)
+        vp.enable_counters(True)
+        vp.read_counters(reset=True)
+        vp.render_frames(buf.ptr, frames[0], len(frames), vP)
+        got = buf.download()
+        c = vp.read_counters()
+        vp.enable_counters(False)
+        buf.free()
+        assert np.array_equal(got, ref), f"max abs diff {np.abs(got - ref).max()}"
+        for k in ("density_lookups", "env_lookups", "scatters", "opacity_lookups"):
+            assert c[k] == cnt[k], (k, c[k], cnt[k])
+        assert cnt["env_lookups"] > cnt["samples"]          # more than the one background lookup per path
+    finally:
+        vp.set_envmap_sampling(vp.ENV_PASSIVE)
+
+
+@pytest.mark.parametrize("est,frame", [(0, 48), (0, 1733), (1, 4452), (2, 4452)])
+def test_mis_zero_pdf_continue_quirk(vp, oracle, est, frame):
+    """kernel.cu:2266 / :1539 / :1900: an environment sample of zero pdf `continue`s the path loop, so the path goes on
+    from the OLD origin in the OLD direction.  It takes a random number of exactly 0 on a black first column; the
+    (estimator, frame) pairs were found by scanning frames with the oracle's hit counter (Philox key (9, 4))."""
+    grid = oracle.julia(32)
+    env = scenes.synthetic_env()
+    env[:, 0, :3] = 0.0
+    osc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, estimator=est, rng_mode=1,
+                             seed=(9, 4), env_mis=True)
+    kw = dict(density=150.0, g=0.6)
+    oP, vP = oracle.default_param(W, H, **kw), vp.make_param(W, H, **kw)
+    osc.precompute_opacity()
+    before = oracle.lib().vpo_debug_mis_zero_pdf()
+    ref, _ = osc.render_frame(oP, frame)
+    assert oracle.lib().vpo_debug_mis_zero_pdf() > before, "this frame no longer takes the zero-pdf branch"
+    try:
+        vp.set_envmap_sampling(vp.ENV_MIS)
+        vp.init_volume(grid, brick=1)
+        vp.init_envmap(env)
+        vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+        vp.set_camera()
+        vp.set_estimator(est)
+        vp.set_rng(1, (9, 4))
+        vp.set_shard(0, 1)
+        vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+        buf = vp.DeviceBuffer(W, H)
+        vp.render_frames(buf.ptr, frame, 1, vP)
+        got = buf.download()
+        buf.free()
+        assert np.array_equal(got, ref), f"max abs diff {np.abs(got - ref).max()}"
+    finally:
+        vp.set_envmap_sampling(vp.ENV_PASSIVE)
+
+
 def test_bad_arguments_are_rejected(vp):
     grid = vp.julia_volume(8)
     vp.init_volume(grid)
