@@ -121,6 +121,10 @@ int vp_set_rng(int mode, uint32_t key0, uint32_t key1); /* default VP_RNG_SAMPLE
  * look the environment up.  VP_ENV_MIS is its compiled-out alternative: luminance CDFs built in init_envmap
  * (kernel.cu:1144-1210) and one-sample MIS between phase-function and environment sampling after each collision
  * (kernel.cu:2220-2297, MULT_PDF 0, PRE_WARP 1); only unscattered paths then see the environment directly. */
+/* render_kernel renders up to max_frames consecutive frames per launch when the host asks for frame f right after f-1 with
+ * unchanged state, stages them, and serves the following calls from the staged frames (bit-identical to one launch per
+ * frame).  Default 64; 0 or 1 = one launch per call.  Env: VP_LOOKAHEAD. */
+int vp_set_lookahead(int max_frames);
 enum { VP_ENV_PASSIVE = 0, VP_ENV_MIS = 1 };
 int vp_set_envmap_sampling(int mode);                  /* default VP_ENV_PASSIVE */
 /* test hook: the tables of the current environment: cdf_y[h], cdf_x[w*h] (row CDFs), HDRpdfnormAlt; any may be NULL */

@@ -397,6 +397,57 @@ def test_mis_zero_pdf_continue_quirk(vp, oracle, est, frame):
         vp.set_envmap_sampling(vp.ENV_PASSIVE)
 
 
+def test_render_kernel_lookahead_is_invisible(vp, oracle):
+    """render_kernel stages frames ahead when called for consecutive frames; every observable state of the accumulator
+    must equal the one-launch-per-frame result: after each call, across state changes, frame jumps and buffer swaps."""
+    grid = oracle.julia(32)
+    osc, oP, vP = _setup(vp, oracle, grid, 1, 1, brick=1, key=(5, 6))
+    osc.precompute_opacity()
+    vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+    vp.set_lookahead(8)
+    try:
+        buf, buf2 = vp.DeviceBuffer(W, H), vp.DeviceBuffer(W, H)
+        ref = np.zeros((H, W, 4), np.float32)
+        # (a) 21 consecutive frames, checked after every call (misses at 0,1,3,7,15 with batches 1,2,4,8,8)
+        for f in range(21):
+            vp.render_kernel(buf.ptr, f, vP)
+            ref, _ = osc.render_frame(oP, f, ref)
+            if f in (0, 1, 2, 6, 7, 14, 15, 20):
+                assert np.array_equal(buf.download(), ref), f"after frame {f}"
+        # (b) the camera moves while frames 21.. are staged: they must be dropped
+        cam = np.array([[0, .3, .95, 3.7], [0, .95, -.3, -.9], [-1, 0, 0, .1]], np.float32)
+        vp.set_camera(cam.ravel().tolist())
+        osc2 = oracle.OracleScene(grid, scenes.synthetic_env(), scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, brick=1,
+                                  estimator=1, rng_mode=1, seed=(5, 6), inv_view=cam)
+        osc2.precompute_opacity()
+        for f in (21, 22, 23):
+            vp.render_kernel(buf.ptr, f, vP)
+            ref, _ = osc2.render_frame(oP, f, ref)
+        assert np.array_equal(buf.download(), ref)
+        # (c) a frame jump, a repeated frame, and a Param change inside a staged run
+        ref2 = np.zeros((H, W, 4), np.float32)
+        vP2 = vp.make_param(W, H, density=300.0)
+        oP2 = oracle.default_param(W, H, density=300.0)
+        for f, (vq, oq) in [(40, (vP, oP)), (41, (vP, oP)), (42, (vP, oP)), (42, (vP, oP)), (43, (vP2, oP2)), (44, (vP2, oP2)),
+                            (45, (vP2, oP2)), (3, (vP2, oP2))]:
+            vp.render_kernel(buf2.ptr, f, vq)
+            ref2, _ = osc2.render_frame(oq, f, ref2)
+        assert np.array_equal(buf2.download(), ref2)
+        # (d) staged frames may go to a different accumulator than the one of the miss
+        buf.reset(); buf2.reset()
+        a = np.zeros((H, W, 4), np.float32); b = np.zeros((H, W, 4), np.float32)
+        for f in range(50, 58):
+            tgt, acc = (buf, "a") if f % 2 == 0 else (buf2, "b")
+            vp.render_kernel(tgt.ptr, f, vP2)
+            if acc == "a": a, _ = osc2.render_frame(oP2, f, a)
+            else: b, _ = osc2.render_frame(oP2, f, b)
+        assert np.array_equal(buf.download(), a) and np.array_equal(buf2.download(), b)
+        buf.free(); buf2.free()
+    finally:
+        vp.set_lookahead(64)
+        vp.set_camera()
+
+
 def test_bad_arguments_are_rejected(vp):
     grid = vp.julia_volume(8)
     vp.init_volume(grid)
