@@ -254,6 +254,36 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void 
 #pragma unroll 1
         for (int rep = 0; rep < 4; rep++)
         {
+            // order: a path that ends here is written, its lane refilled and the new segment set up in ONE round
+            // ---- ray left the medium: background() kernel.cu:1258-1267 (quirk Q11)
+            if (st == EV_BG)
+            {
+                // with active environment sampling only unscattered paths see it directly (kernel.cu:2026-2030, :1340-1344)
+                if (!MIS || nsc == 0)
+                {
+                    f3 bg;
+                    if (nsc == 0 && dot(rd, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
+                    else { bg = eval_envmap(S, rd); if (COUNT) c_env++; }
+                    rad = rad + bg * (ACH ? f3{thr.x, thr.x, thr.x} : thr);
+                }
+                st = EV_WRITE;
+            }
+            // ---- path end: emit the sample (kernel.cu:2306-2316 / :1579-1589)
+            if (st == EV_WRITE)
+            {
+                f3     r    = rad * P.brightness;
+                // heat: num_scatters (:2307) or loop index * 0.001 in double (:1581, :1942)
+                float  heat = (EST == EST_DECOMP) ? (float)nsc : (float)((double)(EST == EST_BOUNDED ? seg : nsc) * 0.001);
+                float4 v    = make_float4(fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f), fmaxf(r.z, 0.0f), heat);
+                if (L.stage) L.stage[item] = v;
+                else
+                {
+                    size_t idx = (size_t)px + (size_t)py * P.width;
+                    float4 a   = L.out[idx];
+                    L.out[idx] = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
+                }
+                st = ST_DONE;
+            }
             // ---- refill finished lanes from the queue.  The wave owns a chunk [chunk_next, chunk_end)
             // of consecutive samples (one atomic per VP_CHUNK samples); idle lanes are compacted
             // with ballot + mbcnt and take the next samples of the chunk.
@@ -338,36 +368,8 @@ __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void 
                     st            = ST_TRACK;
                 }
             }
-            // ---- ray left the medium: background() kernel.cu:1258-1267 (quirk Q11)
-            if (st == EV_BG)
-            {
-                // with active environment sampling only unscattered paths see it directly (kernel.cu:2026-2030, :1340-1344)
-                if (!MIS || nsc == 0)
-                {
-                    f3 bg;
-                    if (nsc == 0 && dot(rd, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
-                    else { bg = eval_envmap(S, rd); if (COUNT) c_env++; }
-                    rad = rad + bg * (ACH ? f3{thr.x, thr.x, thr.x} : thr);
-                }
-                st = EV_WRITE;
-            }
-            // ---- path end: emit the sample (kernel.cu:2306-2316 / :1579-1589)
-            if (st == EV_WRITE)
-            {
-                f3     r    = rad * P.brightness;
-                // heat: num_scatters (:2307) or loop index * 0.001 in double (:1581, :1942)
-                float  heat = (EST == EST_DECOMP) ? (float)nsc : (float)((double)(EST == EST_BOUNDED ? seg : nsc) * 0.001);
-                float4 v    = make_float4(fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f), fmaxf(r.z, 0.0f), heat);
-                if (L.stage) L.stage[item] = v;
-                else
-                {
-                    size_t idx = (size_t)px + (size_t)py * P.width;
-                    float4 a   = L.out[idx];
-                    L.out[idx] = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
-                }
-                st = ST_DONE;
-            }
-            if (__ballot(st == ST_DONE && !exhausted) == 0ull) break;
+            // another round only for lanes this loop can serve: idle ones, and new samples that missed the volume
+            if (__ballot((st == ST_DONE && !exhausted) || st == EV_BG || st == EV_WRITE) == 0ull) break;
         }
         if (__ballot(st != ST_DONE || !exhausted) == 0ull) break;  // queue drained and every lane idle
         if (COUNT) { unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) t_slow += t - t_mark; t_mark = t; }
