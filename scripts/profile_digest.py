@@ -27,4 +27,7 @@ for d in ("kt", "fetch"):
 if "fetch" in res and "write" in res:
     f = res["fetch"]["per_launch"].get("FETCH_SIZE", 0.0); w = res["write"]["per_launch"].get("WRITE_SIZE", 0.0)
     res["hbm_bytes_per_launch_raw"] = (f + w) * 1024.0
+    # gfx950: one fabric read request per distinct 128-byte line, tallied at 64 bytes -- also for this kernel's 8-byte
+    # gathers (scripts/ubench/gather_calib.hip, profiles/r01_fetch_calibration.txt): reads count double
+    res["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
 print(json.dumps(res, indent=1))
