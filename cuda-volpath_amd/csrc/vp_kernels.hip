@@ -45,7 +45,10 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
 // MIS: active environment sampling with one-sample MIS after the sun estimate (the reference's !PASSIVE_ENVMAP
 // build, kernel.cu:2220-2297); the shipped configuration is passive (MIS = false).
 template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool MIS>
-__global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, VP_MIN_WAVES) void render_k(SceneDev S, LaunchDev L)
+// The local-majorant kernels need 98 VGPRs when left alone, two more than five waves per SIMD allow (512 / 5 -> 96):
+// asking for five costs no spill and is +10 % on the reference-table decomposition workload.
+__global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK, (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : ((EST != EST_GLOBAL && !LDSB && !MIS) ? 5 : 1))
+void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
     if (LDSB)
