@@ -81,7 +81,11 @@ struct State
 };
 State G;
 
-size_t kMaxStageBytes = (size_t)1 << 30;  // 1 GiB of per-sample staging per launch (VP_STAGE_MB overrides)
+// Per-sample staging per launch.  A launch ends with a tail in which only the deepest paths are still running
+// (about 14 ms at 800x600 whatever the launch size), so launches should be long: 128 frames per launch (1 GiB) lose
+// 9 % to tails, 1024 frames (8 GB) 1 %.  288 GB of HBM make that cheap; the cap is also held to a quarter of the free
+// memory at allocation time.  VP_STAGE_MB overrides.
+size_t kMaxStageBytes = (size_t)16 << 30;
 
 int fail(int code, const char* fmt, ...)
 {
@@ -330,7 +334,13 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     L.wait_lanes = G.wait_lanes; L.wait_iters = G.wait_iters;
     if (L.ntiles_owned == 0) return VP_OK;
     const size_t per_frame = (size_t)L.ntiles_owned * 64;
-    size_t max_f = kMaxStageBytes / (per_frame * sizeof(float4));
+    size_t stage_cap = kMaxStageBytes;
+    if (nframes > 1 && (size_t)nframes * per_frame * sizeof(float4) > G.stage_bytes)
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) stage_cap = std::min(stage_cap, std::max(G.stage_bytes, (free_b + G.stage_bytes) / 4));
+    }
+    size_t max_f = stage_cap / (per_frame * sizeof(float4));
     if (max_f < 1) max_f = 1;
     size_t cap_items = 0xfffffff0u / per_frame;
     if (cap_items < 1) return fail(VP_E_ARG, "image too large for the 32-bit sample queue");
