@@ -48,8 +48,16 @@ struct State
     // frame look-ahead of render_kernel (see serve_frame): what the staged frames were rendered with
     unsigned long long epoch = 0;     // bumped whenever device CONTENT changes behind unchanged pointers
     int         la_max      = 64;     // most frames rendered ahead per launch; <= 1 switches the look-ahead off
-    bool        la_valid    = false;
-    int         la_first = 0, la_count = 0;
+    struct LaSlot  // one staged batch of frames, rendered on its own stream so that two batches overlap
+    {
+        float4*     buf = nullptr;
+        size_t      bytes = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t  done = nullptr;   // recorded after the batch's render
+        bool        valid = false;
+        int         first = 0, count = 0;
+        std::vector<unsigned char> key;
+    } la[2];
     int         la_prev_n   = 0;      // batch size of the last miss
     int         la_last     = -2;     // frame index of the last render_kernel call
     std::vector<unsigned char> la_key;  // render state of the staged frames / of the last call
@@ -140,9 +148,12 @@ int ensure_device()
     return VP_OK;
 }
 
+int la_quiesce();
+
 int free_volume()
 {
-    G.epoch++;  // staged look-ahead frames no longer describe this scene
+    G.epoch++;  // staged look-ahead frames no longer describe this scene ...
+    (void)la_quiesce();  // ... and batches in flight must not see device buffers change under them
 
     if (G.d_cells) HIPCHK(hipFree(G.d_cells));
     if (G.d_bounds) HIPCHK(hipFree(G.d_bounds));
@@ -160,7 +171,8 @@ int free_volume()
 
 int do_init_volume(const void* h_volume, vp_extent ext, bool quantized, const vp_float3* bmin, const vp_float3* bmax)
 {
-    G.epoch++;  // staged look-ahead frames no longer describe this scene
+    G.epoch++;  // staged look-ahead frames no longer describe this scene ...
+    (void)la_quiesce();  // ... and batches in flight must not see device buffers change under them
 
     int rc = ensure_device();
     if (rc) return rc;
@@ -233,7 +245,8 @@ int do_init_volume(const void* h_volume, vp_extent ext, bool quantized, const vp
 
 int do_opacity(const float* dir)
 {
-    G.epoch++;  // staged look-ahead frames no longer describe this scene
+    G.epoch++;  // staged look-ahead frames no longer describe this scene ...
+    (void)la_quiesce();  // ... and batches in flight must not see device buffers change under them
 
     if (!G.have_volume) return fail(VP_E_STATE, "precompute_opacity before init_cuda");
     size_t n = (size_t)G.S.nx * G.S.ny * G.S.nz;
@@ -250,7 +263,8 @@ int build_env_tables();
 
 int do_envmap(const vp_float4* data, int w, int h)
 {
-    G.epoch++;  // staged look-ahead frames no longer describe this scene
+    G.epoch++;  // staged look-ahead frames no longer describe this scene ...
+    (void)la_quiesce();  // ... and batches in flight must not see device buffers change under them
 
     int rc = ensure_device();
     if (rc) return rc;
@@ -274,7 +288,8 @@ int do_envmap(const vp_float4* data, int w, int h)
 // init_envmap kernel.cu:1144-1210: luminance CDFs and HDRpdfnormAlt for the current environment
 int build_env_tables()
 {
-    G.epoch++;  // staged look-ahead frames no longer describe this scene
+    G.epoch++;  // staged look-ahead frames no longer describe this scene ...
+    (void)la_quiesce();  // ... and batches in flight must not see device buffers change under them
 
     if (G.env_tables || !G.have_env) return VP_OK;
     const int w = G.env_w, h = G.env_h;
@@ -305,7 +320,10 @@ hipEvent_t get_event()
     return e;
 }
 
-int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool stage_only = false)
+// where a render launch goes: the caller's stream with the shared staging buffer, or a look-ahead slot
+struct Target { hipStream_t stream; float4** stage; size_t* stage_bytes; unsigned* queue; };
+
+int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool stage_only = false, const Target* tgt = nullptr)
 {
     int rc = ensure_device();
     if (rc) return rc;
@@ -314,7 +332,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     if (!G.have_sun) return fail(VP_E_STATE, "render before set_sun");
     if (!G.have_cam) return fail(VP_E_STATE, "render before copy_inv_view_matrix");
     if (!d_out || !p || nframes <= 0 || first < 0) return fail(VP_E_ARG, "bad render arguments");
-    if (!stage_only) G.la_valid = false;  // the staging buffer is about to be reused (or stays unused)
+    const Target main_tgt = {G.stream, &G.d_stage, &G.stage_bytes, G.d_queue};
+    const Target& T = tgt ? *tgt : main_tgt;
     if (p->width == 0 || p->height == 0 || p->width > 65535 || p->height > 65535)
         return fail(VP_E_ARG, "image %ux%u out of range (sampler.h packs x<<16|y)", p->width, p->height);
     if (G.est == VP_EST_DECOMP && first + nframes - 1 > 10 && !G.S.opacity)
@@ -328,17 +347,17 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     L.rank = G.rank; L.world = G.world;
     L.ntiles_owned = ntiles > G.rank ? (ntiles - G.rank + G.world - 1) / G.world : 0;
     L.out = (float4*)d_out;
-    L.queue = G.d_queue;
+    L.queue = T.queue;
     L.counters = G.count ? G.d_counters : nullptr;
     L.key0 = G.key0; L.key1 = G.key1;
     L.wait_lanes = G.wait_lanes; L.wait_iters = G.wait_iters;
     if (L.ntiles_owned == 0) return VP_OK;
     const size_t per_frame = (size_t)L.ntiles_owned * 64;
     size_t stage_cap = kMaxStageBytes;
-    if (nframes > 1 && (size_t)nframes * per_frame * sizeof(float4) > G.stage_bytes)
+    if (nframes > 1 && (size_t)nframes * per_frame * sizeof(float4) > *T.stage_bytes)
     {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) stage_cap = std::min(stage_cap, std::max(G.stage_bytes, (free_b + G.stage_bytes) / 4));
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) stage_cap = std::min(stage_cap, std::max(*T.stage_bytes, (free_b + *T.stage_bytes) / 4));
     }
     size_t max_f = stage_cap / (per_frame * sizeof(float4));
     if (max_f < 1) max_f = 1;
@@ -357,18 +376,19 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         if (f > 1 || stage_only)
         {
             size_t need = per_frame * (size_t)f * sizeof(float4);
-            if (need > G.stage_bytes)
+            if (need > *T.stage_bytes)
             {
-                HIPCHK(hipStreamSynchronize(G.stream));
-                if (G.d_stage) HIPCHK(hipFree(G.d_stage));
-                HIPCHK(hipMalloc((void**)&G.d_stage, need));
-                G.stage_bytes = need;
+                HIPCHK(hipStreamSynchronize(T.stream));
+                HIPCHK(hipStreamSynchronize(G.stream));  // add-kernels of earlier frames may still read the old buffer
+                if (*T.stage) HIPCHK(hipFree(*T.stage));
+                HIPCHK(hipMalloc((void**)T.stage, need));
+                *T.stage_bytes = need;
             }
-            L.stage = G.d_stage;
+            L.stage = *T.stage;
         }
         else
             L.stage = nullptr;
-        HIPCHK(hipMemsetAsync(G.d_queue, 0, sizeof(unsigned), G.stream));
+        HIPCHK(hipMemsetAsync(T.queue, 0, sizeof(unsigned), T.stream));
         // the brick table goes through LDS when it fits (decomposition estimator, byte table <= 64 KiB)
         const bool lds_bounds = G.use_lds_bounds && G.est == VP_EST_DECOMP && G.quant && !G.env_mis &&
                                 (size_t)S.bnx * S.bny * S.bnz <= (size_t)VP_LDS_BOUND_ENTRIES;
@@ -378,14 +398,14 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         unsigned cap    = (unsigned)G.num_cu * (lds_bounds ? 2u : G.blocks_per_cu);
         if (blocks > cap) blocks = cap;
         hipEvent_t e0 = get_event(), e1 = get_event();
-        HIPCHK(hipEventRecord(e0, G.stream));
-        launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, (int)blocks, G.stream);
+        HIPCHK(hipEventRecord(e0, T.stream));
+        launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, (int)blocks, T.stream);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(e1, G.stream));
+        HIPCHK(hipEventRecord(e1, T.stream));
         G.events.emplace_back(e0, e1);
         if (L.stage && !stage_only)
         {
-            launch_reduce(L, G.stream);
+            launch_reduce(L, T.stream);
             HIPCHK(hipGetLastError());
         }
         done += f;
@@ -408,9 +428,49 @@ void render_key(const Param* p, std::vector<unsigned char>& key)
 // render_kernel with frame look-ahead.  The reference host calls render_kernel once per frame and synchronises
 // (host.cpp:631-632); a one-frame launch is bound by its longest path (about 14 ms for 0.48 M samples, 12x off the
 // batched rate).  A sample is a pure function of (x, y, frame, scene), so when the host asks for frame f right after
-// f-1 with nothing changed, frames f..f+n-1 are rendered in ONE launch into the staging buffer (n doubles per
-// consecutive miss up to la_max) and only frame f is added to the caller's accumulator; the next calls find their
-// frame staged and just add it.  Any state change drops the staged frames.  Bit-identical to one launch per frame.
+// f-1 with nothing changed, frames f..f+n-1 are rendered in ONE launch into a staging slot (n doubles per consecutive
+// miss up to la_max) and only frame f is added to the caller's accumulator; the next calls find their frame staged and
+// just add it.  Once n has reached la_max two slots are kept in flight on two streams, so the tail of one batch (its
+// deepest paths) overlaps the body of the next.  Any state change drops the staged frames.  Bit-identical to one
+// launch per frame.
+int la_quiesce()
+{
+    for (auto& s : G.la)
+    {
+        if (s.stream) HIPCHK(hipStreamSynchronize(s.stream));
+        s.valid = false;
+    }
+    return VP_OK;
+}
+int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, const std::vector<unsigned char>& key)
+{
+    auto& s = G.la[si];
+    if (!s.stream) HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    if (!s.done) HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    s.valid = false;
+    // after everything queued on the caller's stream: uploads the scene depends on, and add-kernels still reading this slot
+    hipEvent_t ev = get_event();
+    HIPCHK(hipEventRecord(ev, G.stream));
+    HIPCHK(hipStreamWaitEvent(s.stream, ev, 0));
+    G.event_pool.push_back(ev);
+    const Target t = {s.stream, &s.buf, &s.bytes, G.d_queue + 16 * (si + 1)};
+    int rc = do_render(d_out, first, n, p, true, &t);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(s.done, s.stream));
+    s.valid = true; s.first = first; s.count = n; s.key = key;
+    return VP_OK;
+}
+int la_limit(int first, int n, size_t per_frame)
+{
+    if (G.est == VP_EST_DECOMP && !G.S.opacity) n = first <= 10 ? std::min(n, 11 - first) : 0;  // quirk Q5 needs the opacity volume
+    if (per_frame && n > 0)
+    {
+        size_t fit = kMaxStageBytes / (per_frame * sizeof(float4));
+        fit = std::min<size_t>(fit, 0xfffffff0u / per_frame);
+        n = (int)std::min<size_t>((size_t)n, std::max<size_t>(fit, 1));
+    }
+    return n;
+}
 int serve_frame(vp_float4* d_out, int frame, const Param* p)
 {
     if (G.la_max <= 1 || G.count || !p) return do_render(d_out, frame, 1, p);
@@ -418,17 +478,30 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
     if (rc) return rc;
     std::vector<unsigned char> key;
     render_key(p, key);
-    const bool same = key == G.la_key;
     const unsigned tiles_x = (p->width + 7) / 8, tiles_y = (p->height + 7) / 8, ntiles = tiles_x * tiles_y;
     const unsigned owned = ntiles > G.rank ? (ntiles - G.rank + G.world - 1) / G.world : 0;
     const size_t per_frame = (size_t)owned * 64;
-    if (G.la_valid && same && d_out && frame >= G.la_first && frame < G.la_first + G.la_count && per_frame)
+    for (int si = 0; si < 2 && d_out && per_frame; si++)
     {
+        auto& s = G.la[si];
+        if (!(s.valid && s.key == key && frame >= s.first && frame < s.first + s.count)) continue;
+        // entering a full-size batch: the other slot is free, start the batch after this one.  Queued BEFORE this
+        // frame's wait on its own batch, so that the new batch depends only on work already on the caller's stream
+        // (the add-kernels that read the other slot) and can fill the tail of the batch now finishing.
+        auto& o = G.la[si ^ 1];
+        const int next = s.first + s.count;
+        if (frame == s.first && s.count >= G.la_max && !(o.valid && o.key == key && o.first == next))
+        {
+            int n = la_limit(next, G.la_max, per_frame);
+            if (n > 1 && la_render_slot(si ^ 1, d_out, next, n, p, key)) G.la[si ^ 1].valid = false;  // best effort
+        }
+        // hit: add the staged frame once its batch is rendered
+        HIPCHK(hipStreamWaitEvent(G.stream, s.done, 0));
         LaunchDev L = {};
         memcpy(&L.P, p, sizeof(Param));
         L.tiles_x = tiles_x; L.tiles_y = tiles_y; L.rank = G.rank; L.world = G.world; L.ntiles_owned = owned;
         L.out = (float4*)d_out;
-        L.stage = G.d_stage + (size_t)(frame - G.la_first) * per_frame;
+        L.stage = s.buf + (size_t)(frame - s.first) * per_frame;
         L.nframes = 1;
         launch_reduce(L, G.stream);
         HIPCHK(hipGetLastError());
@@ -436,20 +509,15 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
         return VP_OK;
     }
     // miss: how far ahead?  only when this call continues the previous one
+    const bool same = key == G.la_key;
     int n = (same && frame == G.la_last + 1) ? std::min(std::max(G.la_prev_n, 1) * 2, G.la_max) : 1;
-    if (G.est == VP_EST_DECOMP && !G.S.opacity && frame <= 10) n = std::min(n, 11 - frame);  // quirk Q5 needs the opacity volume
-    if (per_frame)
-    {
-        size_t fit = kMaxStageBytes / (per_frame * sizeof(float4));
-        fit = std::min<size_t>(fit, 0xfffffff0u / per_frame);
-        n = (int)std::min<size_t>((size_t)n, std::max<size_t>(fit, 1));
-    }
+    if (n > 1) n = std::max(la_limit(frame, n, per_frame), 1);
     G.la_key = key; G.la_last = frame; G.la_prev_n = n;
-    if (n <= 1 || !per_frame) return do_render(d_out, frame, 1, p);
-    rc = do_render(d_out, frame, n, p, true);
-    if (rc) { G.la_valid = false; return rc; }
-    G.la_valid = true; G.la_first = frame; G.la_count = n;
-    return serve_frame(d_out, frame, p);  // now a hit
+    G.la[0].valid = G.la[1].valid = false;
+    if (n <= 1 || !per_frame || !d_out) return do_render(d_out, frame, 1, p);
+    rc = la_render_slot(0, d_out, frame, n, p, key);
+    if (rc) return rc;
+    return serve_frame(d_out, frame, p);  // now a hit (which also starts the following batch once n is full size)
 }
 }  // namespace
 
@@ -489,6 +557,7 @@ void free_envmap(void)
 {
     if (!G.have_env) return;
     G.epoch++;
+    (void)la_quiesce();
     (void)hipStreamSynchronize(G.stream);
     (void)hipFree(G.d_env);
     (void)hipFree(G.d_env_cdf_x);
@@ -561,6 +630,7 @@ int vp_set_stream(void* s)
     int rc = ensure_device();
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(G.stream));
+    if (la_quiesce()) return VP_E_NODEVICE;
     G.stream = s ? (hipStream_t)s : G.own_stream;
     return VP_OK;
 }
@@ -586,7 +656,8 @@ int vp_set_rng(int mode, uint32_t k0, uint32_t k1)
 int vp_set_lookahead(int max_frames)
 {
     if (max_frames < 0 || max_frames > 4096) return fail(VP_E_ARG, "look-ahead of %d frames out of range [0,4096]", max_frames);
-    G.la_max = max_frames; G.la_valid = false; G.la_prev_n = 0;
+    if (la_quiesce()) return VP_E_NODEVICE;
+    G.la_max = max_frames; G.la_prev_n = 0;
     return VP_OK;
 }
 int vp_set_envmap_sampling(int mode)
@@ -648,6 +719,8 @@ int vp_render_time_ms(double* total_ms, int* launches, int reset)
     int rc = ensure_device();
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(G.stream));
+    for (auto& sl : G.la)  // look-ahead batches still in flight are launches too
+        if (sl.stream) HIPCHK(hipStreamSynchronize(sl.stream));
     double tot = 0;
     for (auto& ev : G.events)
     {
