@@ -94,6 +94,7 @@ State G;
 // 9 % to tails, 1024 frames (8 GB) 1 %.  288 GB of HBM make that cheap; the cap is also held to a quarter of the free
 // memory at allocation time.  VP_STAGE_MB overrides.
 size_t kMaxStageBytes = (size_t)16 << 30;
+constexpr size_t kQueueWords = VP_NQUEUES * VP_QUEUE_STRIDE;  // queue heads of one launch
 
 int fail(int code, const char* fmt, ...)
 {
@@ -132,7 +133,7 @@ int ensure_device()
     G.num_cu = prop.multiProcessorCount;
     HIPCHK(hipStreamCreateWithFlags(&G.own_stream, hipStreamNonBlocking));
     if (!G.stream) G.stream = G.own_stream;
-    HIPCHK(hipMalloc((void**)&G.d_queue, 256));
+    HIPCHK(hipMalloc((void**)&G.d_queue, 3 * kQueueWords * sizeof(unsigned)));  // caller's stream + two look-ahead slots
     HIPCHK(hipMalloc((void**)&G.d_counters, 16 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(G.d_counters, 0, 16 * sizeof(unsigned long long)));
     G.S.sun_cos = 94.0f / sqrtf(94.0f * 94.0f + 0.45f * 0.45f);                    // kernel.cu:1263
@@ -353,6 +354,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     L.wait_lanes = G.wait_lanes; L.wait_iters = G.wait_iters;
     if (L.ntiles_owned == 0) return VP_OK;
     const size_t per_frame = (size_t)L.ntiles_owned * 64;
+    // the owned tiles (row-major) split into VP_NQUEUES bands of whole tiles
+    for (unsigned q = 0; q <= VP_NQUEUES; q++) L.q_start[q] = (unsigned)((unsigned long long)L.ntiles_owned * q / VP_NQUEUES) * 64u;
     size_t stage_cap = kMaxStageBytes;
     if (nframes > 1 && (size_t)nframes * per_frame * sizeof(float4) > *T.stage_bytes)
     {
@@ -388,7 +391,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         }
         else
             L.stage = nullptr;
-        HIPCHK(hipMemsetAsync(T.queue, 0, sizeof(unsigned), T.stream));
+        HIPCHK(hipMemsetAsync(T.queue, 0, kQueueWords * sizeof(unsigned), T.stream));
         // the brick table goes through LDS when it fits (decomposition estimator, byte table <= 64 KiB)
         const bool lds_bounds = G.use_lds_bounds && G.est == VP_EST_DECOMP && G.quant && !G.env_mis &&
                                 (size_t)S.bnx * S.bny * S.bnz <= (size_t)VP_LDS_BOUND_ENTRIES;
@@ -453,7 +456,7 @@ int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, c
     HIPCHK(hipEventRecord(ev, G.stream));
     HIPCHK(hipStreamWaitEvent(s.stream, ev, 0));
     G.event_pool.push_back(ev);
-    const Target t = {s.stream, &s.buf, &s.bytes, G.d_queue + 16 * (si + 1)};
+    const Target t = {s.stream, &s.buf, &s.bytes, G.d_queue + kQueueWords * (si + 1)};
     int rc = do_render(d_out, first, n, p, true, &t);
     if (rc) return rc;
     HIPCHK(hipEventRecord(s.done, s.stream));

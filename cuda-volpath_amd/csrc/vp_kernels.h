@@ -12,7 +12,11 @@
 #define VP_MIN_WAVES 1                // launch-bounds hint: waves per SIMD the register budget must allow
 #endif
 #define VP_LDS_BOUND_ENTRIES 32768     // (max,min) byte pairs staged in LDS: 64 KiB
-#define VP_CHUNK 256  // samples a wave takes from the global queue per atomic
+#define VP_CHUNK 256  // samples a wave takes from a queue per atomic
+// One sample queue per XCD: each hands out a contiguous band of the image (all frames of it), so the rays an XCD's
+// L2 serves stay in one slab of the volume; a wave starts on the queue of its own XCD and moves on when it runs dry.
+#define VP_NQUEUES 8
+#define VP_QUEUE_STRIDE 16  // words between queue heads (one cache line each)
 // the inner tracking loop of a wave runs until this many lanes are parked on an event, or until
 // a parked lane has waited this many steps
 #ifndef VP_WAIT_LANES
@@ -42,7 +46,8 @@ struct LaunchDev
     unsigned total_items;  // nframes * ntiles_owned * 64
     float4*  out;          // W*H accumulator (caller-owned)
     float4*  stage;        // [nframes][ntiles_owned*64] per-sample results, or null = accumulate directly
-    unsigned* queue;       // sample queue head (zeroed before the launch)
+    unsigned* queue;       // VP_NQUEUES sample-queue heads, VP_QUEUE_STRIDE words apart (zeroed before the launch)
+    unsigned q_start[VP_NQUEUES + 1];  // slot range [q_start[q], q_start[q+1]) of a frame that queue q hands out
     unsigned long long* counters;  // 6 words (samples, density, bound, opacity, env, scatters) or null
     unsigned key0, key1;   // Philox key
     unsigned wait_lanes, wait_iters;  // inner-loop exit policy (VP_WAIT_LANES / VP_WAIT_ITERS)

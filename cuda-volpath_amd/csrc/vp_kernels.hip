@@ -101,6 +101,9 @@ void render_k(SceneDev S, LaunchDev L)
     const unsigned lane = threadIdx.x & 63u;
     unsigned chunk_next = 0, chunk_end = 0;  // wave-uniform
     bool     queue_empty = false;
+    // the queue this wave draws from: its XCD's first (HW_REG_XCC_ID, bits 3:0), then the others in turn
+    unsigned q_cur   = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & (VP_NQUEUES - 1);
+    unsigned q_tried = 0;
 
     for (;;)
     {
@@ -295,16 +298,28 @@ void render_k(SceneDev S, LaunchDev L)
                 unsigned long long m    = __ballot(need);
                 if (m)
                 {
-                    if (chunk_next >= chunk_end && !queue_empty)
+                    while (chunk_next >= chunk_end && !queue_empty)
                     {
-                        unsigned base = 0;
-                        if (lane == 0) base = atomicAdd(L.queue, (unsigned)VP_CHUNK);
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        if (base >= L.total_items) { queue_empty = true; chunk_next = chunk_end = L.total_items; }
+                        // queue q_cur: chunk c is chunk (c % cpf) of its band in frame (c / cpf)
+                        const unsigned q0 = L.q_start[q_cur], len = L.q_start[q_cur + 1] - q0;
+                        const unsigned cpf = (len + (unsigned)VP_CHUNK - 1) / (unsigned)VP_CHUNK;
+                        unsigned c = 0xffffffffu;
+                        if (len)
+                        {
+                            if (lane == 0) c = atomicAdd(L.queue + q_cur * VP_QUEUE_STRIDE, 1u);
+                            c = __builtin_amdgcn_readfirstlane(c);
+                        }
+                        if (c < cpf * (unsigned)L.nframes)
+                        {
+                            const unsigned fl = c / cpf, off = (c - fl * cpf) * (unsigned)VP_CHUNK;
+                            chunk_next = fl * (L.ntiles_owned * 64u) + q0 + off;
+                            chunk_end  = chunk_next + (len - off < (unsigned)VP_CHUNK ? len - off : (unsigned)VP_CHUNK);
+                        }
                         else
                         {
-                            chunk_next = base;
-                            chunk_end  = (L.total_items - base < (unsigned)VP_CHUNK) ? L.total_items : base + (unsigned)VP_CHUNK;
+                            // this band is handed out: help with the next one
+                            q_cur = (q_cur + 1) & (VP_NQUEUES - 1);
+                            if (++q_tried >= VP_NQUEUES) queue_empty = true;
                         }
                     }
                     unsigned cnt   = (unsigned)__popcll(m);
