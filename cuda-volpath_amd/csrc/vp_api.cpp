@@ -80,7 +80,7 @@ struct State
     unsigned long long* d_counters = nullptr;
     bool        count       = false;
     unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS;
-    unsigned    blocks_per_cu = 5;  // resident 256-thread workgroups per CU: 6+ waves per SIMD thrash L2 (measured 359 vs 268 Msamples/s)
+    unsigned    blocks_per_cu = 6;  // resident 256-thread workgroups per CU (the register budget of each kernel decides how many really are)
     bool        use_lds_bounds = true;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> event_pool;
