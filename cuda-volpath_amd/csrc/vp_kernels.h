@@ -12,7 +12,9 @@
 #define VP_MIN_WAVES 1                // launch-bounds hint: waves per SIMD the register budget must allow
 #endif
 #define VP_LDS_BOUND_ENTRIES 32768     // (max,min) byte pairs staged in LDS: 64 KiB
+#ifndef VP_CHUNK
 #define VP_CHUNK 256  // samples a wave takes from a queue per atomic
+#endif
 // One sample queue per XCD: each hands out a contiguous band of the image (all frames of it), so the rays an XCD's
 // L2 serves stay in one slab of the volume; a wave starts on the queue of its own XCD and moves on when it runs dry.
 #define VP_NQUEUES 8
