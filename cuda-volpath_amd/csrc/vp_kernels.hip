@@ -1,13 +1,16 @@
 // vp_kernels.hip -- gfx950 kernels of the volumetric radiance integrator.
 //
-// render_k: persistent wave64 workgroups pull (frame, pixel) samples from a global queue with
-// one atomic per wave (ballot + mbcnt compaction), so a lane whose path ended is refilled while
+// render_k: persistent wave64 workgroups pull (frame, pixel) samples from per-XCD queues with one
+// atomic per 256 samples (ballot + mbcnt compaction), so a lane whose path ended is refilled while
 // its neighbours keep tracking; every path carries its own RNG state and therefore computes the
-// same bits wherever and whenever it runs.  One loop iteration = at most one segment set-up, one
-// free-flight step (primary or shadow ray) and one event.  Restates
+// same bits wherever and whenever it runs.  A wave alternates between an inner loop of free-flight
+// steps (four per pass; segment set-up included for the local-majorant estimators) and an event
+// pass that serves the lanes parked on collisions, light estimates, exits and refills.  Restates
 //   __d_render_bounded_decomp  kernel.cu:1958-2318  (EST_DECOMP, the reference's live kernel)
 //   __d_render                 kernel.cu:1285-1591  (EST_GLOBAL, BASELINE config 2)
-// under SPECTRAL_TRACKING=1, SUN_LIGHT=1, PASSIVE_ENVMAP=1, PRECOMPUTE_OPACITY=1 (kernel.cu:15-34).
+//   __d_render_bounded         kernel.cu:1667-1952  (EST_BOUNDED, dead in the reference)
+// under SPECTRAL_TRACKING=1, SUN_LIGHT=1, PRECOMPUTE_OPACITY=1 (kernel.cu:15-34), with PASSIVE_ENVMAP=1
+// (MIS = false, the shipped build) or 0 (MIS = true).
 #include <hip/hip_runtime.h>
 
 #include "vp_device.h"
