@@ -62,6 +62,7 @@ struct State
     int         la_last     = -2;     // frame index of the last render_kernel call
     std::vector<unsigned char> la_key;  // render state of the staged frames / of the last call
     // active environment sampling (!PASSIVE_ENVMAP): CDF tables, built on demand
+    int         trk         = 0;      // VP_TRACK_*: spectral (shipped), scalar, multi-channel
     bool        env_mis     = false;
     bool        env_tables  = false;  // tables match the current envmap
     float*      d_env_cdf_x = nullptr;
@@ -337,6 +338,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     const Target& T = tgt ? *tgt : main_tgt;
     if (p->width == 0 || p->height == 0 || p->width > 65535 || p->height > 65535)
         return fail(VP_E_ARG, "image %ux%u out of range (sampler.h packs x<<16|y)", p->width, p->height);
+    if (G.trk && G.env_mis) return fail(VP_E_STATE, "scalar tracking builds exist with passive environment lighting only");
+    if (G.trk && G.count) return fail(VP_E_STATE, "work counters are not built for the scalar tracking kernels");
     if (G.est == VP_EST_DECOMP && first + nframes - 1 > 10 && !G.S.opacity)
         return fail(VP_E_NOOPACITY, "frames beyond 10 need precompute_opacity (kernel.cu:2183, host.cpp:336-343)");
     LaunchDev L = {};
@@ -393,7 +396,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             L.stage = nullptr;
         HIPCHK(hipMemsetAsync(T.queue, 0, kQueueWords * sizeof(unsigned), T.stream));
         // the brick table goes through LDS when it fits (decomposition estimator, byte table <= 64 KiB)
-        const bool lds_bounds = G.use_lds_bounds && G.est == VP_EST_DECOMP && G.quant && !G.env_mis &&
+        const bool lds_bounds = G.use_lds_bounds && G.est == VP_EST_DECOMP && G.quant && !G.env_mis && !G.trk &&
                                 (size_t)S.bnx * S.bny * S.bnz <= (size_t)VP_LDS_BOUND_ENTRIES;
         const unsigned bsz = lds_bounds ? VP_BLOCK_LDS : VP_BLOCK;
         unsigned waves  = (L.total_items + 63) / 64;
@@ -402,7 +405,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         if (blocks > cap) blocks = cap;
         hipEvent_t e0 = get_event(), e1 = get_event();
         HIPCHK(hipEventRecord(e0, T.stream));
-        launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, (int)blocks, T.stream);
+        launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, G.trk, (int)blocks, T.stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, T.stream));
         G.events.emplace_back(e0, e1);
@@ -419,12 +422,12 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
 // everything a sample's value depends on besides (x, y, frame): compared bytewise between render_kernel calls
 void render_key(const Param* p, std::vector<unsigned char>& key)
 {
-    struct K { SceneDev S; Param P; int est, rng, linear, quant, mis; unsigned k0, k1, rank, world; unsigned long long epoch; };
+    struct K { SceneDev S; Param P; int est, rng, linear, quant, mis, trk; unsigned k0, k1, rank, world; unsigned long long epoch; };
     key.assign(sizeof(K), 0);
     K* k = reinterpret_cast<K*>(key.data());
     memcpy(&k->S, &G.S, sizeof(SceneDev));
     memcpy(&k->P, p, sizeof(Param));
-    k->est = G.est; k->rng = G.rng; k->linear = G.linear; k->quant = G.quant; k->mis = G.env_mis;
+    k->est = G.est; k->rng = G.rng; k->linear = G.linear; k->quant = G.quant; k->mis = G.env_mis; k->trk = G.trk;
     k->k0 = G.key0; k->k1 = G.key1; k->rank = G.rank; k->world = G.world; k->epoch = G.epoch;
 }
 
@@ -654,6 +657,13 @@ int vp_set_rng(int mode, uint32_t k0, uint32_t k1)
 {
     if (mode != VP_RNG_SAMPLERH && mode != VP_RNG_PHILOX) return fail(VP_E_ARG, "unknown rng %d", mode);
     G.rng = mode; G.key0 = k0; G.key1 = k1;
+    return VP_OK;
+}
+int vp_set_tracking(int mode)
+{
+    if (mode != VP_TRACK_SPECTRAL && mode != VP_TRACK_SCALAR && mode != VP_TRACK_MULTI_CHANNEL)
+        return fail(VP_E_ARG, "unknown tracking mode %d", mode);
+    G.trk = mode;
     return VP_OK;
 }
 int vp_set_lookahead(int max_frames)

@@ -55,8 +55,8 @@ struct LaunchDev
     unsigned wait_lanes, wait_iters;  // inner-loop exit policy (VP_WAIT_LANES / VP_WAIT_ITERS)
 };
 
-void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int blocks,
-                   hipStream_t st);
+void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
+                   int blocks, hipStream_t st);
 void launch_env_tables(const float4* env, int w, int h, float* lum, float* row_sum, float* cdf_x, float* cdf_y, float* pdfnorm_alt,
                        hipStream_t st);
 void launch_reduce(const LaunchDev& L, hipStream_t st);

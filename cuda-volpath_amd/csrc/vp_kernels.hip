@@ -47,12 +47,14 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
 // formed from one product, (m + m) + m, exactly as the three-channel expression evaluates.
 // MIS: active environment sampling with one-sample MIS after the sun estimate (the reference's !PASSIVE_ENVMAP
 // build, kernel.cu:2220-2297); the shipped configuration is passive (MIS = false).
-template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool MIS>
+// TRK: 0 = spectral tracking (SPECTRAL_TRACKING 1, the shipped build); 1 = scalar tracking (SPECTRAL_TRACKING 0);
+// 2 = MULTI_CHANNEL 1: scalar tracking of one colour channel drawn per sample (kernel.cu:15-34, :1993-1994, :2311-2313).
+template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool MIS, int TRK>
 // The local-majorant kernels need 98 VGPRs when left alone, two more than five waves per SIMD allow (512 / 5 -> 96):
 // asking for five costs no spill and is +10 % on the reference-table decomposition workload.  The global-majorant
 // kernel fits six waves (80 VGPRs, no spill): +3 % now that the queue order keeps the L2 hit rate above 90 %.
 __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK,
-                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (MIS || LDSB ? 1 : (EST == EST_GLOBAL ? 6 : 5)))
+                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (MIS || LDSB ? 1 : (EST == EST_GLOBAL && ACH && TRK == 0 ? 6 : 5)))
 void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
@@ -98,6 +100,9 @@ void render_k(SceneDev S, LaunchDev L)
     f3       nee_c = {}, nee_t = {}, seg_o = {};
     int      nee_stage = 0;
     float    sh_inv_sigma = 0, sh_density = 0;
+    // scalar tracking only: the sample's extinction coefficient (density, or density * sigma_t[chan]) and its channel
+    float    sig_base = density;
+    int      chan = 0;
 
     unsigned long long c_den = 0, c_bnd = 0, c_opa = 0, c_env = 0, c_sca = 0, c_smp = 0;
     unsigned long long d_iter = 0, d_act = 0, d_outer = 0, d_shadow = 0;  // debug (lane 0 counts wave events)
@@ -152,7 +157,13 @@ void render_k(SceneDev S, LaunchDev L)
             // "to match passive result": post-increment count (DECOMP :2168) / i-4 (GLOBAL :1465)
             float s2 = hyperion_s((LOCAL) ? (nsc - 5) : (nsc - 4));
             float dp2, stp2;
-            if (LOCAL)
+            if (TRK)
+            {
+                thr  = thr * f3{P.albedo[0], P.albedo[1], P.albedo[2]};  // kernel.cu:2157-2159
+                stp2 = LOCAL ? ((1.0f - s2) + s2 * (1.0f - P.g)) * sig_base : (1.0f - s2) * sig_base + s2 * sig_base * (1.0f - P.g);
+                dp2  = stp2;  // Tr(..., inv_sigma, sigma_t_prime, rng): the coefficient is the "density" of the shadow ray
+            }
+            else if (LOCAL)
             {
                 float reduction2 = (1.0f - s2) + s2 * (1.0f - P.g);
                 dp2              = reduction2 * density;
@@ -179,8 +190,16 @@ void render_k(SceneDev S, LaunchDev L)
                 // precomputed optical depth kernel.cu:2183-2189 (quirk Q5)
                 float op = sample_float_volume(S, S.opacity, ro);
                 if (COUNT) c_opa++;
-                f3 tau = (f3{-sig_t.x, -sig_t.y, -sig_t.z} * dp2) * op;
-                nee_a  = f3{expf_(tau.x), expf_(tau.y), expf_(tau.z)};
+                if (TRK)
+                {
+                    float a = expf_(-stp2 * op);  // kernel.cu:2190
+                    nee_a   = f3{a, a, a};
+                }
+                else
+                {
+                    f3 tau = (f3{-sig_t.x, -sig_t.y, -sig_t.z} * dp2) * op;
+                    nee_a  = f3{expf_(tau.x), expf_(tau.y), expf_(tau.z)};
+                }
                 st     = EV_NEE;
             }
             else
@@ -286,6 +305,8 @@ void render_k(SceneDev S, LaunchDev L)
                 // heat: num_scatters (:2307) or loop index * 0.001 in double (:1581, :1942)
                 float  heat = (EST == EST_DECOMP) ? (float)nsc : (float)((double)(EST == EST_BOUNDED ? seg : nsc) * 0.001);
                 float4 v    = make_float4(fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f), fmaxf(r.z, 0.0f), heat);
+                if (TRK == 2)  // kernel.cu:2311-2313: the drawn channel only, times three
+                    v = make_float4(chan == 0 ? v.x * 3.0f : 0.0f, chan == 1 ? v.y * 3.0f : 0.0f, chan == 2 ? v.z * 3.0f : 0.0f, heat);
                 if (L.stage) L.stage[item] = v;
                 else
                 {
@@ -352,6 +373,11 @@ void render_k(SceneDev S, LaunchDev L)
                             {
                                 // camera ray, kernel.cu:1977-1987 (quirk Q3)
                                 rng.init(px, py, (unsigned)frame, L.key0, L.key1);
+                                if (TRK == 2)
+                                {
+                                    chan     = (int)fminf((1.0f - rng.next_a()) * 3.0f, 2.9999998f);  // kernel.cu:1993
+                                    sig_base = density * (chan == 0 ? P.sigma_t[0] : chan == 1 ? P.sigma_t[1] : P.sigma_t[2]);
+                                }
                                 float u = ((float)px * 2.0f - (float)P.width) / (float)P.width;
                                 float v = ((float)py * 2.0f - (float)P.height) / (float)P.width;
                                 ro      = f3{S.cam[3], S.cam[7], S.cam[11]};
@@ -386,8 +412,16 @@ void render_k(SceneDev S, LaunchDev L)
                     dist          = t_near;
                     float s       = hyperion_s(nsc - 5);
                     phase_g       = (1.0f - s) * P.g;
-                    cur_density   = (1.0f - s) * density + s * density * (1.0f - P.g);
-                    sigma_t_prime = max_sig * cur_density;
+                    if (TRK)
+                    {
+                        sigma_t_prime = (1.0f - s) * sig_base + s * sig_base * (1.0f - P.g);  // kernel.cu:1363
+                        cur_density   = sigma_t_prime;  // vol_sigma_t(pos, sigma_t_prime), kernel.cu:1436
+                    }
+                    else
+                    {
+                        cur_density   = (1.0f - s) * density + s * density * (1.0f - P.g);
+                        sigma_t_prime = max_sig * cur_density;
+                    }
                     inv_sigma     = 1.0f / sigma_t_prime;
                     inv_sigma_t   = inv_sigma;
                     st            = ST_TRACK;
@@ -433,10 +467,18 @@ void render_k(SceneDev S, LaunchDev L)
                     float s         = hyperion_s(nsc - 5);
                     phase_g         = (1.0f - s) * P.g;
                     float reduction = (1.0f - s) + s * (1.0f - P.g);
-                    cur_density     = reduction * density;
-                    sigma_t_prime   = max_sig * cur_density * d_max;
+                    if (TRK)
+                    {
+                        sigma_t_prime = reduction * sig_base;  // kernel.cu:2063 / :1745: no local bound in the scalar build
+                        cur_density   = sigma_t_prime;
+                    }
+                    else
+                    {
+                        cur_density   = reduction * density;
+                        sigma_t_prime = max_sig * cur_density * d_max;
+                    }
                     inv_sigma_t     = 1.0f / sigma_t_prime;
-                    if (EST == EST_DECOMP && d_min > 0.0f)
+                    if (TRK == 0 && EST == EST_DECOMP && d_min > 0.0f)
                     {
                         // analog decomposition tracking kernel.cu:2048-2054 (quirk Q7)
                         sigma_c       = min_sig * cur_density * d_min;
@@ -493,7 +535,16 @@ void render_k(SceneDev S, LaunchDev L)
                     float den = sample_density01<QUANT>(S, p) * cur_density;  // vol_sigma_t kernel.cu:682-695
                     float e   = rng.next_b();
                     if (COUNT) c_den++;
-                    if (shadow)
+                    if (TRK)
+                    {
+                        // scalar delta tracking: kernel.cu:2137-2142 / :745-748 (Tr stops AT its collision, no further draw)
+                        if (e < den * inv_sigma)
+                        {
+                            if (shadow) { nee_a = f3{0.0f, 0.0f, 0.0f}; st = EV_NEE; }
+                            else { ro = p; st = EV_SCATTER; }
+                        }
+                    }
+                    else if (shadow)
                     {
                         // kernel.cu:791-805
                         if (ACH) terms = (e < sig_t.x * den * inv_sigma) ? 7 : terms;
@@ -827,13 +878,30 @@ static void launch_render5(const SceneDev& S, const LaunchDev& L, bool quant, bo
     const dim3 blk(LDSB ? VP_BLOCK_LDS : VP_BLOCK);
     if (quant)
     {
-        if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB, ACH, MIS>), dim3(blocks), blk, 0, st, S, L);
-        else hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB, ACH, MIS>), dim3(blocks), blk, 0, st, S, L);
+        if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB, ACH, MIS, 0>), dim3(blocks), blk, 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB, ACH, MIS, 0>), dim3(blocks), blk, 0, st, S, L);
     }
     else
     {
-        if (count) hipLaunchKernelGGL((render_k<EST, RNG, false, true, false, ACH, MIS>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
-        else hipLaunchKernelGGL((render_k<EST, RNG, false, false, false, ACH, MIS>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+        if (count) hipLaunchKernelGGL((render_k<EST, RNG, false, true, false, ACH, MIS, 0>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, false, false, false, ACH, MIS, 0>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+    }
+}
+// scalar tracking builds (the reference's compiled-out SPECTRAL_TRACKING 0 / MULTI_CHANNEL 1): three-channel throughput, no
+// LDS / MIS / counting specialisations
+template <int EST, class RNG>
+static void launch_render_scalar(const SceneDev& S, const LaunchDev& L, bool quant, int trk, int blocks, hipStream_t st)
+{
+    const dim3 blk(VP_BLOCK);
+    if (quant)
+    {
+        if (trk == 1) hipLaunchKernelGGL((render_k<EST, RNG, true, false, false, false, false, 1>), dim3(blocks), blk, 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, true, false, false, false, false, 2>), dim3(blocks), blk, 0, st, S, L);
+    }
+    else
+    {
+        if (trk == 1) hipLaunchKernelGGL((render_k<EST, RNG, false, false, false, false, false, 1>), dim3(blocks), blk, 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, false, false, false, false, false, 2>), dim3(blocks), blk, 0, st, S, L);
     }
 }
 template <int EST, class RNG, bool LDSB>
@@ -849,9 +917,17 @@ static void launch_render3(const SceneDev& S, const LaunchDev& L, bool quant, bo
     else launch_render5<EST, RNG, LDSB, false, false>(S, L, quant, count, blocks, st);
 }
 
-void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int blocks,
-                   hipStream_t st)
+void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
+                   int blocks, hipStream_t st)
 {
+    if (trk)
+    {
+        const bool ph = rng == RNG_PHILOX;
+        if (est == EST_DECOMP) { if (ph) launch_render_scalar<EST_DECOMP, RngPhilox>(S, L, quant, trk, blocks, st); else launch_render_scalar<EST_DECOMP, RngSamplerH>(S, L, quant, trk, blocks, st); }
+        else if (est == EST_BOUNDED) { if (ph) launch_render_scalar<EST_BOUNDED, RngPhilox>(S, L, quant, trk, blocks, st); else launch_render_scalar<EST_BOUNDED, RngSamplerH>(S, L, quant, trk, blocks, st); }
+        else { if (ph) launch_render_scalar<EST_GLOBAL, RngPhilox>(S, L, quant, trk, blocks, st); else launch_render_scalar<EST_GLOBAL, RngSamplerH>(S, L, quant, trk, blocks, st); }
+        return;
+    }
     // achromatic medium: identical extinction and albedo in the three channels (e.g. preset #13, host.cpp:1308)
     const ParamDev& P = L.P;
     const bool ach = P.sigma_t[0] == P.sigma_t[1] && P.sigma_t[1] == P.sigma_t[2] && P.albedo[0] == P.albedo[1] &&

@@ -16,13 +16,14 @@ LIB_PATH = os.environ.get("VOLPATH_LIB", os.path.join(os.path.dirname(_HERE), "l
 EST_GLOBAL, EST_DECOMP, EST_BOUNDED = 0, 1, 2
 RNG_SAMPLERH, RNG_PHILOX = 0, 1
 ENV_PASSIVE, ENV_MIS = 0, 1
+TRACK_SPECTRAL, TRACK_SCALAR, TRACK_MULTI_CHANNEL = 0, 1, 2
 
 # every symbol include/volpath.h declares (tests check the library exports each one)
 PART1_SYMBOLS = ["init_cuda", "set_texture_filter_mode", "free_cuda_buffers", "precompute_opacity", "init_envmap",
                  "free_envmap", "set_sun", "copy_inv_view_matrix", "copy_inv_model_matrix", "init_rng", "free_rng",
                  "render_kernel", "scale", "gamma_correct"]
 PART2_SYMBOLS = ["vp_last_error", "vp_version", "vp_device_count", "vp_set_device", "vp_set_stream", "vp_synchronize",
-                 "vp_set_estimator", "vp_set_rng", "vp_set_envmap_sampling", "vp_get_env_tables", "vp_set_lookahead", "vp_set_bound_brick", "vp_set_shard", "vp_render_frames",
+                 "vp_set_estimator", "vp_set_rng", "vp_set_envmap_sampling", "vp_get_env_tables", "vp_set_lookahead", "vp_set_tracking", "vp_set_bound_brick", "vp_set_shard", "vp_render_frames",
                  "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity",
                  "vp_julia_voxelize", "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_malloc", "vp_free", "vp_memset",
                  "vp_upload", "vp_download"]
@@ -233,6 +234,11 @@ def set_estimator(est):
 
 def set_rng(mode, key=(0, 0)):
     _chk(lib().vp_set_rng(mode, key[0], key[1]))
+
+
+def set_tracking(mode):
+    """TRACK_SPECTRAL (shipped) / TRACK_SCALAR (SPECTRAL_TRACKING 0) / TRACK_MULTI_CHANNEL (MULTI_CHANNEL 1)"""
+    _chk(lib().vp_set_tracking(mode))
 
 
 def set_lookahead(max_frames):

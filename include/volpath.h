@@ -121,6 +121,14 @@ int vp_set_rng(int mode, uint32_t key0, uint32_t key1); /* default VP_RNG_SAMPLE
  * look the environment up.  VP_ENV_MIS is its compiled-out alternative: luminance CDFs built in init_envmap
  * (kernel.cu:1144-1210) and one-sample MIS between phase-function and environment sampling after each collision
  * (kernel.cu:2220-2297, MULT_PDF 0, PRE_WARP 1); only unscattered paths then see the environment directly. */
+/* Collision sampling.  VP_TRACK_SPECTRAL is the reference's shipped build (SPECTRAL_TRACKING 1, kernel.cu:15-34): one path
+ * for the three channels with history-aware collision probabilities.  The other two are its compiled-out alternatives:
+ * VP_TRACK_SCALAR = SPECTRAL_TRACKING 0 (one extinction coefficient = density, throughput *= albedo per collision, scalar
+ * shadow rays), VP_TRACK_MULTI_CHANNEL = MULTI_CHANNEL 1 (the same with coefficient density * sigma_t[channel], the channel
+ * drawn per sample and written times three, kernel.cu:1993-1994, :2311-2313).  Both ignore the local bound (kernel.cu:2063)
+ * and exist with VP_ENV_PASSIVE only. */
+enum { VP_TRACK_SPECTRAL = 0, VP_TRACK_SCALAR = 1, VP_TRACK_MULTI_CHANNEL = 2 };
+int vp_set_tracking(int mode);                         /* default VP_TRACK_SPECTRAL */
 /* render_kernel renders up to max_frames consecutive frames per launch when the host asks for frame f right after f-1 with
  * unchanged state, stages them, and serves the following calls from the staged frames (bit-identical to one launch per
  * frame).  Default 64; 0 or 1 = one launch per call.  Env: VP_LOOKAHEAD. */

@@ -1114,12 +1114,161 @@ static void sample_global(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
     out[3] = (float)((double)i * 0.001); /* heat = i * 0.001, kernel.cu:1582 */
 }
 
+/* -------------------------- scalar tracking: SPECTRAL_TRACKING 0 / MULTI_CHANNEL 1 -- */
+/* Tr kernel.cu:712-751: the scalar shadow ray; stops AT its first collision (no further draw) */
+static float tr_scalar(const vpo_scene* S, f3 bmin, f3 bmax, f3 start, f3 end, float inv_sigma, float density,
+                       rng_t* rng, vpo_counters* C)
+{
+    f3    o = start;
+    f3    d = normalize3(sub3(end, start));
+    float t_near, t_far;
+    if (!intersect_box(o, d, bmin, bmax, &t_near, &t_far)) return 1.0f;
+    if (t_near < 0.0f) t_near = 0.0f;
+    float max_t = fminf(t_far, length3(sub3(start, end)));
+    float dist  = t_near;
+    for (;;)
+    {
+        dist += -vpo_logf(rng_next_a(rng)) * inv_sigma;
+        if (dist >= max_t) break;
+        f3 pos = add3(o, muls(d, dist));
+        if (rng_next_b(rng) < vol_sigma_t(S, pos, density, C) * inv_sigma) break;
+    }
+    return (float)(dist >= max_t);
+}
+
+/* The three kernels compiled with SPECTRAL_TRACKING 0 (track_mode 1) or MULTI_CHANNEL 1 (track_mode 2), both compiled
+ * out in the shipped reference (kernel.cu:15-34).  One extinction coefficient -- density, or density * sigma_t[channel]
+ * with the channel drawn per sample (:1993-1994) -- classic delta tracking against the Hyperion-reduced coefficient WITHOUT
+ * the local bound (the bound is still fetched by intersectSuperVolume), throughput *= albedo per collision, scalar
+ * shadow rays.  A1 :2063/:2101-2143/:2157-2215, A3 :1745/:1797-1817, A2 :1363/:1435-1455; PASSIVE_ENVMAP 1 only. */
+static void sample_scalar(const vpo_scene* S, const vpo_param* P, uint32_t x, uint32_t y, int spp, float out[4],
+                          vpo_counters* C)
+{
+    const int   est        = S->estimator;
+    const float density    = P->density;
+    const float brightness = P->brightness;
+    f3 boxMin = mk3(S->box_min[0], S->box_min[1], S->box_min[2]);
+    f3 boxMax = mk3(S->box_max[0], S->box_max[1], S->box_max[2]);
+    f3 sun_dir   = mk3(S->sun_dir[0], S->sun_dir[1], S->sun_dir[2]);
+    f3 sun_power = mk3(S->sun_power[0], S->sun_power[1], S->sun_power[2]);
+    f3 albedo    = mk3(P->albedo[0], P->albedo[1], P->albedo[2]);
+
+    rng_t rng;
+    rng_init(&rng, S, x, y, (uint32_t)spp, &C->rng_draws);
+    f3 cr_o, cr_d;
+    camera_ray(S, P, x, y, &cr_o, &cr_d);
+    f3 radiance   = mk3(0, 0, 0);
+    f3 throughput = mk3(1, 1, 1);
+
+    int   channel = 0;
+    float sigma_t = density;
+    if (S->track_mode == 2)
+    {
+        channel = (int)fminf((1.0f - rng_next_a(&rng)) * 3.0f, 2.9999998f); /* :1993 */
+        sigma_t = density * P->sigma_t[channel];
+    }
+
+    int num_scatters = 0; /* A1, A3 */
+    int i = 0;            /* loop index of A2, A3 */
+    for (;;)
+    {
+        if (est == VPO_EST_DECOMP ? !(num_scatters < 800) : !(i < 800)) break;
+        const int depth = est == VPO_EST_GLOBAL ? i : num_scatters; /* what hyperion and background see */
+        float t_near, t_far, d_min, d_max;
+        int   hit;
+        if (est == VPO_EST_GLOBAL)
+        {
+            hit = intersect_box(cr_o, cr_d, boxMin, boxMax, &t_near, &t_far);
+            if (hit && t_near < 0.0f) t_near = 0.0f;
+        }
+        else
+            hit = intersect_super_volume(S, cr_o, cr_d, boxMin, boxMax, &t_near, &t_far, &d_min, &d_max, C);
+        if (!hit)
+        {
+            radiance = add3(radiance, mul3(background(S, cr_d, depth, C), throughput));
+            break;
+        }
+        f3    pos;
+        float dist = t_near;
+        float s = hyperion_s(depth - 5);
+        float g = (1.0f - s) * P->g;
+        float sigma_t_prime = est == VPO_EST_GLOBAL ? (1.0f - s) * sigma_t + s * sigma_t * (1.0f - P->g)
+                                                    : ((1.0f - s) + s * (1.0f - P->g)) * sigma_t;
+        float inv_sigma = 1.0f / sigma_t_prime;
+        int   through = 0;
+        for (;;)
+        {
+            dist += -vpo_logf(rng_next_a(&rng)) * inv_sigma;
+            if (dist >= t_far) { through = 1; break; }
+            pos = add3(cr_o, muls(cr_d, dist));
+            if (rng_next_b(&rng) < vol_sigma_t(S, pos, sigma_t_prime, C) * inv_sigma)
+            {
+                if (est != VPO_EST_GLOBAL) ++num_scatters;
+                break;
+            }
+        }
+        if (through)
+        {
+            if (est == VPO_EST_GLOBAL)
+            {
+                radiance = add3(radiance, mul3(background(S, cr_d, i, C), throughput)); /* :1446-1452 */
+                break;
+            }
+            cr_o = add3(cr_o, muls(cr_d, t_far));
+            if (est == VPO_EST_BOUNDED) i++;
+            continue;
+        }
+        C->scatters++;
+        throughput = mul3(throughput, albedo);
+
+        frame_t frame = make_frame(cr_d);
+        {
+            float s2 = hyperion_s(est == VPO_EST_GLOBAL ? i - 4 : num_scatters - 5);
+            float sigma_t_prime2 = est == VPO_EST_GLOBAL ? (1.0f - s2) * sigma_t + s2 * sigma_t * (1.0f - P->g)
+                                                         : ((1.0f - s2) + s2 * (1.0f - P->g)) * sigma_t;
+            float inv_sigma2 = 1.0f / sigma_t_prime2;
+            float ph = vpo_hg_eval(g, dot3(frame.n, sun_dir));
+            float a;
+            if (est == VPO_EST_DECOMP && spp > 10 && num_scatters > 20)
+            {
+                C->opacity_lookups++;
+                a = vpo_expf(-sigma_t_prime2 * sample_volume(S, NULL, S->opacity, 1, pos)); /* :2190 */
+            }
+            else
+                a = tr_scalar(S, boxMin, boxMax, pos, muls(sun_dir, 1e10f), inv_sigma2, sigma_t_prime2, &rng, C);
+            radiance = add3(radiance, mul3(sun_power, muls(muls(throughput, ph), a)));
+        }
+        float r0 = rng_next_a(&rng);
+        float r1 = rng_next_b(&rng);
+        f3 new_dir = normalize3(frame_to_world(&frame, hg_sample_local(g, r0, r1)));
+        cr_o = pos;
+        cr_d = new_dir;
+        if (est != VPO_EST_DECOMP) i++;
+    }
+    radiance = muls(radiance, brightness);
+    float heat = est == VPO_EST_DECOMP ? (float)num_scatters : (float)((double)i * 0.001);
+    if (S->track_mode == 2)
+    {
+        float r[3] = {radiance.x, radiance.y, radiance.z};
+        out[0] = out[1] = out[2] = 0.0f;
+        out[channel] = fmaxf(r[channel], 0.0f) * 3.0f; /* :2311-2313 */
+    }
+    else
+    {
+        out[0] = fmaxf(radiance.x, 0.0f);
+        out[1] = fmaxf(radiance.y, 0.0f);
+        out[2] = fmaxf(radiance.z, 0.0f);
+    }
+    out[3] = heat;
+}
+
 void vpo_render_sample(const vpo_scene* S, const vpo_param* P, int x, int y, int frame, float out[4],
                        vpo_counters* C)
 {
     vpo_counters local;
     memset(&local, 0, sizeof local);
-    if (S->estimator == VPO_EST_DECOMP) sample_decomp(S, P, (uint32_t)x, (uint32_t)y, frame, out, &local);
+    if (S->track_mode) sample_scalar(S, P, (uint32_t)x, (uint32_t)y, frame, out, &local);
+    else if (S->estimator == VPO_EST_DECOMP) sample_decomp(S, P, (uint32_t)x, (uint32_t)y, frame, out, &local);
     else if (S->estimator == VPO_EST_BOUNDED) sample_bounded(S, P, (uint32_t)x, (uint32_t)y, frame, out, &local);
     else sample_global(S, P, (uint32_t)x, (uint32_t)y, frame, out, &local);
     local.samples = 1;

@@ -68,6 +68,8 @@ typedef struct
     const float* env_cdf_y; /* env_h */
     const float* env_cdf_x; /* env_w * env_h */
     float        env_pdfnorm_alt;
+    /* 0 = SPECTRAL_TRACKING 1 (shipped); 1 = SPECTRAL_TRACKING 0; 2 = MULTI_CHANNEL 1 (kernel.cu:15-34); 1 and 2 with env_mis 0 only */
+    int          track_mode;
 } vpo_scene;
 
 typedef struct

@@ -34,7 +34,7 @@ class Scene(C.Structure):
                 ("inv_view", C.c_float * 12),
                 ("estimator", C.c_int), ("rng_mode", C.c_int), ("seed", C.c_uint32 * 2),
                 ("env_mis", C.c_int), ("env_cdf_y", C.c_void_p), ("env_cdf_x", C.c_void_p),
-                ("env_pdfnorm_alt", C.c_float)]
+                ("env_pdfnorm_alt", C.c_float), ("track_mode", C.c_int)]
 
 
 class Counters(C.Structure):
@@ -118,7 +118,7 @@ class OracleScene:
 
     def __init__(self, grid, env, sun_dir, sun_power, box=None, brick=1, radius=None, linear=True,
                  estimator=EST_DECOMP, rng_mode=RNG_SAMPLERH, seed=(0, 0), inv_view=None, extra_dilate=None,
-                 env_mis=False):
+                 env_mis=False, track_mode=0):
         L = lib()
         self.grid = np.ascontiguousarray(grid)
         nz, ny, nx = self.grid.shape
@@ -157,6 +157,7 @@ class OracleScene:
         else:
             S.inv_view[:] = list(np.asarray(inv_view, np.float32).ravel())
         S.estimator, S.rng_mode = estimator, rng_mode
+        S.track_mode = track_mode
         S.seed[:] = seed
         self.S = S
         self.opacity = None

@@ -172,6 +172,25 @@ def test_env_tables_and_mis_estimate(oracle):
     assert np.allclose(imgs[0], imgs[1], rtol=0.05)
 
 
+def test_scalar_tracking_modes_estimate_the_same_image(oracle):
+    """SPECTRAL_TRACKING 0 and MULTI_CHANNEL 1 (compiled out in the reference) against the shipped spectral build: for an
+    achromatic medium all three are estimators of the same image."""
+    g = oracle.julia(32)
+    env = scenes.synthetic_env()
+    for est in (oracle.EST_DECOMP, oracle.EST_GLOBAL, oracle.EST_BOUNDED):
+        imgs = []
+        for tm in (0, 1, 2):
+            sc = oracle.OracleScene(g, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, estimator=est,
+                                    rng_mode=oracle.RNG_PHILOX, seed=(4, tm), track_mode=tm)
+            sc.precompute_opacity()   # frames beyond 10 read it in the live kernel (quirk Q5)
+            P = oracle.default_param(64, 48, density=60.0)
+            acc = None
+            for f in range(40):
+                acc, _ = sc.render_frame(P, f, acc)
+            imgs.append(acc[..., :3].mean(axis=(0, 1)) / 40)
+        assert np.allclose(imgs[0], imgs[1], rtol=0.04) and np.allclose(imgs[0], imgs[2], rtol=0.06), (est, imgs)
+
+
 def test_math_accuracy(oracle):
     rng = np.random.default_rng(1)
     u = rng.random(200000).astype(np.float32)

@@ -397,6 +397,40 @@ def test_mis_zero_pdf_continue_quirk(vp, oracle, est, frame):
         vp.set_envmap_sampling(vp.ENV_PASSIVE)
 
 
+@pytest.mark.parametrize("est", [1, 0, 2])
+@pytest.mark.parametrize("track,rng_mode", [(1, 0), (2, 1), (2, 0), (1, 1)])
+def test_scalar_tracking_builds_bit_exact(vp, oracle, est, track, rng_mode):
+    """The reference's compiled-out SPECTRAL_TRACKING 0 (track 1) and MULTI_CHANNEL 1 (track 2) builds of all three kernels."""
+    grid = oracle.julia(32)
+    env = scenes.synthetic_env()
+    osc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, estimator=est, rng_mode=rng_mode,
+                             seed=(2, 8), track_mode=track)
+    kw = dict(density=200.0, g=0.5, albedo=(0.9, 0.8, 0.7), sigma_t=(1.0, 0.7, 0.45))
+    oP, vP = oracle.default_param(W, H, **kw), vp.make_param(W, H, **kw)
+    try:
+        vp.set_tracking(track)
+        vp.init_volume(grid, brick=1)
+        vp.init_envmap(env)
+        vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+        vp.set_camera()
+        vp.set_estimator(est)
+        vp.set_rng(rng_mode, (2, 8))
+        vp.set_shard(0, 1)
+        osc.precompute_opacity()
+        vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+        frames = range(8, 14)     # across the frame > 10 opacity switch of the live kernel
+        ref, _ = _oracle_frames(osc, oP, frames)
+        buf = vp.DeviceBuffer(W, H)
+        vp.render_frames(buf.ptr, frames[0], len(frames), vP)
+        got = buf.download()
+        buf.free()
+        assert np.array_equal(got, ref), f"max abs diff {np.abs(got - ref).max()}"
+        if track == 2:
+            assert ((got[..., :3] > 0).sum(-1) <= len(frames)).all()   # one channel per sample
+    finally:
+        vp.set_tracking(vp.TRACK_SPECTRAL)
+
+
 def test_render_kernel_lookahead_is_invisible(vp, oracle):
     """render_kernel stages frames ahead when called for consecutive frames; every observable state of the accumulator
     must equal the one-launch-per-frame result: after each call, across state changes, frame jumps and buffer swaps."""
