@@ -21,6 +21,7 @@ static void usage()
 {
     printf("volpath_render [--julia N | --bin file.bin | --vdb file.vdb] [--size W H] [--spp N] [--preset 0..12]\n"
            "               [--density D] [--g G] [--estimator decomp|global|bounded] [--brick B] [--rng samplerh|philox]\n"
+           "               [--tracking spectral|scalar|multichannel] [--env passive|mis]\n"
            "               [--sun X Y] [--batch F] [--out name(.ppm|.hdr)]\n");
 }
 
@@ -29,7 +30,7 @@ int main(int argc, char** argv)
     int         julia = 128, W = 400, H = 300, spp = 16, preset = 12, brick = 1, batch = 0;
     float       density = 800.0f, g = 0.877f, sunx = 0.5f, suny = 0.2f;
     bool        philox = false;
-    int         est = VP_EST_DECOMP;
+    int         est = VP_EST_DECOMP, tracking = VP_TRACK_SPECTRAL, env_mode = VP_ENV_PASSIVE;
     std::string bin, vdb, out = "output0.ppm";
     for (int i = 1; i < argc; i++)
     {
@@ -51,6 +52,13 @@ int main(int argc, char** argv)
         }
         else if (a == "--brick") { need(1); brick = atoi(argv[++i]); }
         else if (a == "--rng") { need(1); philox = !strcmp(argv[++i], "philox"); }
+        else if (a == "--tracking")
+        {
+            need(1);
+            const char* t = argv[++i];
+            tracking = !strcmp(t, "scalar") ? VP_TRACK_SCALAR : !strcmp(t, "multichannel") ? VP_TRACK_MULTI_CHANNEL : VP_TRACK_SPECTRAL;
+        }
+        else if (a == "--env") { need(1); env_mode = !strcmp(argv[++i], "mis") ? VP_ENV_MIS : VP_ENV_PASSIVE; }
         else if (a == "--sun") { need(2); sunx = (float)atof(argv[++i]); suny = (float)atof(argv[++i]); }
         else if (a == "--batch") { need(1); batch = atoi(argv[++i]); }
         else if (a == "--out") { need(1); out = argv[++i]; }
@@ -95,6 +103,7 @@ int main(int argc, char** argv)
     set_sun(&sky.sun_dir.x, &sky.sun_power.x);
 
     vp_set_estimator(est);
+    if (vp_set_tracking(tracking) || vp_set_envmap_sampling(env_mode)) { fprintf(stderr, "%s\n", vp_last_error()); return 1; }
     vp_set_rng(philox ? VP_RNG_PHILOX : VP_RNG_SAMPLERH, 0x9E3779B9u, 0x85EBCA6Bu);
 
     // ---- frame buffer (CudaFrameBuffer host.cpp:358-389)
