@@ -95,6 +95,16 @@ def oracle_renders():
             if est == O.EST_DECOMP and rng == O.RNG_SAMPLERH:
                 out["opacity32"] = sc.opacity.astype(np.float32)
                 out["bounds32_r1"] = sc.bounds
+    # the compiled-out builds of the reference's switches: active environment sampling (MIS) and scalar tracking
+    for tag, kw in (("mis", dict(env_mis=True)), ("scalar", dict(track_mode=1)), ("multichannel", dict(track_mode=2))):
+        sc = O.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, estimator=O.EST_DECOMP,
+                           rng_mode=O.RNG_PHILOX, seed=(123, 456), **kw)
+        sc.precompute_opacity()
+        P = O.default_param(64, 48, density=150.0, g=0.6, albedo=(0.9, 0.8, 0.7), sigma_t=(1.0, 0.7, 0.45))
+        acc = None
+        for f in range(8, 14):
+            acc, _ = sc.render_frame(P, f, acc)
+        out[f"decomp_philox_{tag}_f8_13"] = acc
     # chromatic preset #1 with the brick table
     g64 = O.julia(64)
     sc = O.OracleScene(g64, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, brick=8)

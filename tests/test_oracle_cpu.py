@@ -86,6 +86,15 @@ def test_golden_renders_regression(oracle):
             for f in range(14):
                 acc, _ = sc.render_frame(P, f, acc)
             assert np.array_equal(acc, GOLD[f"{name}_{rname}_f0_13"]), (name, rname)
+    for tag, kw in (("mis", dict(env_mis=True)), ("scalar", dict(track_mode=1)), ("multichannel", dict(track_mode=2))):
+        sc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, estimator=oracle.EST_DECOMP,
+                                rng_mode=oracle.RNG_PHILOX, seed=(123, 456), **kw)
+        sc.precompute_opacity()
+        P = oracle.default_param(64, 48, density=150.0, g=0.6, albedo=(0.9, 0.8, 0.7), sigma_t=(1.0, 0.7, 0.45))
+        acc = None
+        for f in range(8, 14):
+            acc, _ = sc.render_frame(P, f, acc)
+        assert np.array_equal(acc, GOLD[f"decomp_philox_{tag}_f8_13"]), tag
 
 
 def test_thread_count_invariance(oracle):

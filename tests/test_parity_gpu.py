@@ -156,6 +156,22 @@ def test_against_committed_golden_vectors(vp, oracle):
     tab, _, _ = vp.bound_table()
     assert np.array_equal(tab, gold["bounds32_r1"])
     assert np.array_equal(vp.opacity_table((32, 32, 32)), gold["opacity32"])
+    # the compiled-out builds
+    kw = dict(density=150.0, g=0.6, albedo=(0.9, 0.8, 0.7), sigma_t=(1.0, 0.7, 0.45))
+    try:
+        for tag, track, envm in (("mis", 0, 1), ("scalar", 1, 0), ("multichannel", 2, 0)):
+            vp.set_tracking(track)
+            vp.set_envmap_sampling(envm)
+            vp.init_envmap(env)
+            vp.set_estimator(1)
+            vp.set_rng(1, (123, 456))
+            buf = vp.DeviceBuffer(W, H)
+            vp.render_frames(buf.ptr, 8, 6, vp.make_param(W, H, **kw))
+            assert np.array_equal(buf.download(), gold[f"decomp_philox_{tag}_f8_13"]), tag
+            buf.free()
+    finally:
+        vp.set_tracking(0)
+        vp.set_envmap_sampling(0)
 
 
 def test_scale_and_gamma_kernels(vp, oracle):
