@@ -54,14 +54,19 @@ def cpu_baseline(workload, seconds_hint=20.0):
     osc = O.OracleScene(grid, env, sun_dir, sun_power,
                         brick=cfg["brick"], estimator=cfg["est"], rng_mode=O.RNG_PHILOX, seed=(0x9E3779B9, 0x85EBCA6B))
     P = O.default_param(cfg["width"], cfg["height"])
+    if cfg["chromatic"]:
+        O.mat(P, *vscene.PRESET1)
     cores = effective_cores()
     nframes, acc, tot, t0 = 0, None, 0, time.time()
     budget = seconds_hint
+    # the live kernel reads the optical-depth volume from frame 11 on (quirk Q5); its CPU precompute costs minutes at
+    # 256^3, so the sample of that estimator stays within frames 0..10
+    max_frames = 11 if cfg["est"] == O.EST_DECOMP else 16
     while True:
         acc, c = osc.render_frame(P, nframes, acc, threads=cores)
         tot += c.samples
         nframes += 1
-        if time.time() - t0 > budget or nframes >= 16:
+        if time.time() - t0 > budget or nframes >= max_frames:
             break
     dt = time.time() - t0
     return {"value": tot / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",

@@ -150,3 +150,17 @@ def test_dense_dump_roundtrip_and_quantisers(host, tmp_path):
     open(str(tmp_path / "bad.bin"), "wb").write(struct.pack("<iii", -1, 2, 2))
     assert host.load_binary(str(tmp_path / "bad.bin")) is None
     assert host.load_vdb(str(tmp_path / "missing.vdb")) is None
+
+
+def test_bench_cpu_baseline_leg_runs_for_every_estimator(host):
+    """bench.py's cpu_baseline (the oracle timed on the host) must work for the decomposition workloads too: their
+    sample stays within frames 0..10, before the live kernel starts reading the optical-depth volume (quirk Q5)."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "cuda-volpath_amd"))
+    spec = importlib.util.spec_from_file_location("vp_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r = bench.cpu_baseline("c1", seconds_hint=60.0)      # Julia 128^3, 400x300, decomposition: 11 frames
+    assert r["kind"] == "port" and r["value"] > 0 and "frames 0..10" in r["sample"]
