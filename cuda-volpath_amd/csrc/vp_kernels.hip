@@ -143,11 +143,23 @@ void render_k(SceneDev S, LaunchDev L)
             }
         };
         // the path goes on with a new segment; loop bounds kernel.cu:34 with :2015 / :1332 / :1716
+        // Local-majorant estimators: the Hyperion-reduced phase function and density of a segment (kernel.cu:2038-2046)
+        // depend on the scatter count only, which restarts do not change: set where the count changes, not per restart.
+        auto segment_medium = [&]() __attribute__((always_inline)) {
+            if (LOCAL)
+            {
+                float s         = hyperion_s(nsc - 5);
+                phase_g         = (1.0f - s) * P.g;
+                float reduction = (1.0f - s) + s * (1.0f - P.g);
+                cur_density     = TRK ? reduction * sig_base : reduction * density;  // scalar build: the coefficient itself (:2063)
+            }
+        };
         auto next_segment = [&]() __attribute__((always_inline)) {
             st = ST_SETUP;
             if (EST == EST_GLOBAL) nsc++;
             if (EST == EST_BOUNDED) seg++;
             if ((EST == EST_BOUNDED ? seg : nsc) >= 800) st = EV_WRITE;
+            segment_medium();
         };
         // ---- collision: direct lighting set-up (kernel.cu:2161-2217 / :1458-1491)
         if (st == EV_SCATTER)
@@ -390,6 +402,7 @@ void render_k(SceneDev S, LaunchDev L)
                                 nsc = 0;
                                 seg = 0;
                                 st  = ST_SETUP;
+                                segment_medium();
                                 if (COUNT) c_smp++;
                             }
                             // pixels of a partial edge tile outside the image: nothing to do, stay DONE
@@ -463,21 +476,10 @@ void render_k(SceneDev S, LaunchDev L)
                 if (!hit) st = EV_BG;
                 else
                 {
-                    dist            = t_near;
-                    float s         = hyperion_s(nsc - 5);
-                    phase_g         = (1.0f - s) * P.g;
-                    float reduction = (1.0f - s) + s * (1.0f - P.g);
-                    if (TRK)
-                    {
-                        sigma_t_prime = reduction * sig_base;  // kernel.cu:2063 / :1745: no local bound in the scalar build
-                        cur_density   = sigma_t_prime;
-                    }
-                    else
-                    {
-                        cur_density   = reduction * density;
-                        sigma_t_prime = max_sig * cur_density * d_max;
-                    }
-                    inv_sigma_t     = 1.0f / sigma_t_prime;
+                    dist          = t_near;
+                    // phase_g and cur_density of this scatter count: segment_medium().  Scalar build: no local bound (:2063 / :1745)
+                    sigma_t_prime = TRK ? cur_density : max_sig * cur_density * d_max;
+                    inv_sigma_t   = 1.0f / sigma_t_prime;
                     if (TRK == 0 && EST == EST_DECOMP && d_min > 0.0f)
                     {
                         // analog decomposition tracking kernel.cu:2048-2054 (quirk Q7)
