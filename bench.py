@@ -5,7 +5,7 @@
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A step = one complete render job of the Julia-256^3 scene at 800x600: `spp` samples per pixel,
-pixel tiles dealt round-robin over the ranks, followed (N > 1) by one RCCL reduce of the HDR
+pixel tiles dealt over the ranks (vp_tile_owner), followed (N > 1) by one RCCL reduce of the HDR
 accumulators to rank 0.  spp = 1024 * N, so every GPU always integrates 800*600*1024 samples per
 step ("weak" scaling); at N = 1 this is BASELINE.json's configs[1] exactly.  Inputs are resident
 in HBM before the timed region.  Prints ONE JSON line on rank 0.
@@ -20,6 +20,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "cuda-volpath_amd"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# vector-instruction issue peak of the chip: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
+# (= 157.3 TFLOP/s fp32 / 2 flops / 64 lanes, same guide)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
+# bytes per sample of the REFERENCE's live estimator on Julia-256^3 800x600 (97.6 density + 51.3
+# bound + 1.0 environment lookups): 8*97.6 + 2*51.3 + 16*1.0 + 32.  Quoted next to this build's own figure so that a
+# workload that does more (C2's global majorant: ~525 lookups) or less work per sample is not mis-read as bandwidth.
+REFERENCE_ESTIMATOR_BYTES_PER_SAMPLE = 8 * 97.6 + 2 * 51.3 + 16 * 1.0 + 32
 
 
 def algorithmic_bytes_per_sample(c):
@@ -57,11 +64,15 @@ def cpu_baseline(workload, seconds_hint=20.0):
     if cfg["chromatic"]:
         O.mat(P, *vscene.PRESET1)
     cores = effective_cores()
+    # the live kernel reads the optical-depth volume from frame 11 on (quirk Q5).  Its CPU precompute is an N^4 march
+    # (minutes at 256^3 and above), so the timed sample stays within frames 0..10 there and says so; at 128^3 the table is
+    # built (untimed) and the sample runs across the switch.
+    across_q5 = cfg["est"] == O.EST_DECOMP and cfg["n"] <= 128
+    if across_q5:
+        osc.precompute_opacity()
+    max_frames = 16 if (cfg["est"] != O.EST_DECOMP or across_q5) else 11
     nframes, acc, tot, t0 = 0, None, 0, time.time()
     budget = seconds_hint
-    # the live kernel reads the optical-depth volume from frame 11 on (quirk Q5); its CPU precompute costs minutes at
-    # 256^3, so the sample of that estimator stays within frames 0..10
-    max_frames = 11 if cfg["est"] == O.EST_DECOMP else 16
     while True:
         acc, c = osc.render_frame(P, nframes, acc, threads=cores)
         tot += c.samples
@@ -71,7 +82,9 @@ def cpu_baseline(workload, seconds_hint=20.0):
     dt = time.time() - t0
     return {"value": tot / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"frames 0..{nframes - 1} of {cfg['width']}x{cfg['height']} ({tot} samples, {dt:.1f} s, "
-                      f"OpenMP over rows, Philox streams)"}
+                      f"OpenMP over rows, Philox streams"
+                      + ("; frames 11+ would read the optical-depth table, whose CPU precompute is not affordable here)"
+                         if cfg["est"] == O.EST_DECOMP and not across_q5 else ")")}
 
 
 def main():
@@ -163,22 +176,39 @@ def main():
         dt = time.perf_counter() - t0
         kern_ms, launches = vp.render_time_ms(reset=True)
 
-    t = torch.tensor([dt], device=torch.device("cpu") if rehearsal else dev, dtype=torch.float64)
+    kern_ms, launches = max(kern_ms, 1e-9), max(launches, 1)
+    # per-rank diagnostics: wall time of the timed region and kernel time of each rank (rank order), so that an N > 1 line
+    # shows whether the tile deal balanced the work
+    t = torch.tensor([dt, kern_ms], device=torch.device("cpu") if rehearsal else dev, dtype=torch.float64)
+    per_rank = [t.clone() for _ in range(world)] if world > 1 else [t]
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        dist.all_gather(per_rank, t)
+    walls = [float(x[0]) for x in per_rank]
+    kerns = [float(x[1]) for x in per_rank]
+    dt = max(walls)
 
     if rank == 0:
         samples_total = float(W) * H * spp_step * args.steps           # all ranks together
         samples_rank = float(W) * H * args.spp * args.steps             # this rank (its tiles)
         value = samples_total / dt / 1e6
-        launch_ms = kern_ms / max(launches, 1)
-        bytes_per_launch = bytes_per_sample * samples_rank / max(launches, 1)
+        launch_ms = kern_ms / launches
+        bytes_per_launch = bytes_per_sample * samples_rank / launches
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        traffic = None
+        # counters of the render kernel from the committed rocprofv3 PMC passes of THIS workload (not measured in this
+        # run: PMC collection serialises kernels); scaled to this run's launch size
+        pmc, traffic, valu_frac, lane_util, pmc_src = {}, None, None, None, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
-            traffic = json.load(open(tp)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            pmc = json.load(open(tp)).get(args.workload, {})
+        if pmc:
+            ref_samples = float(pmc["launch"].split("(")[1].split()[0])
+            scale = (samples_rank / launches) / ref_samples
+            traffic = pmc.get("hbm_bytes_per_launch") and pmc["hbm_bytes_per_launch"] * scale
+            if pmc.get("valu_insts_per_launch"):
+                valu_frac = pmc["valu_insts_per_launch"] * scale / (launch_ms * 1e-3) / VALU_ISSUE_PEAK
+            lane_util = pmc.get("lane_util")
+            pmc_src = f"{pmc.get('source')} @ {pmc.get('commit')} (rocprofv3 --pmc passes of `bench.py --workload {args.workload}`; " \
+                      f"fabric-side counters, Infinity-Cache hits included)"
         out = {
             "metric": "Msamples/sec (WxHxspp) + achieved HBM GB/s, Julia 256^3 @ 800x600",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,13 +220,24 @@ def main():
                        "bound_brick": info["brick"], "rng": args.rng,
                        "parallelism": f"pixel-tiles x{world}" + (" + RCCL reduce" if world > 1 else ""),
                        "sky": "Hosek sun/sky bake, setup_sunsky(0.5, 0.2), 1024x512"},
+            # bound/achieved/peak/frac: the contract's HBM roofline on ALGORITHMIC bytes.  What really bounds this kernel is
+            # vector-instruction issue and lane utilisation (bounded_by, valu_issue_frac, lane_util): its working set is
+            # cache-resident and the measured fabric traffic is below the algorithmic bytes.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
+                         "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic else None,
+                         "bounded_by": "valu_issue", "valu_issue_frac": valu_frac, "valu_issue_peak_per_s": VALU_ISSUE_PEAK,
+                         "lane_util": lane_util,
                          "kernel": "vp::render_k", "launch_ms": launch_ms, "launches": launches,
                          "algorithmic_bytes_per_sample": bytes_per_sample,
+                         "reference_estimator_bytes_per_sample": REFERENCE_ESTIMATOR_BYTES_PER_SAMPLE,
                          "lookups_per_sample": {k: counters[k] / max(counters["samples"], 1) for k in
                                                 ("density_lookups", "bound_lookups", "opacity_lookups", "env_lookups", "scatters")}},
         }
+        if world > 1:
+            mean_k = sum(kerns) / world
+            out["ranks"] = {"wall_s": walls, "kernel_ms": kerns, "balance_max_over_mean": max(kerns) / mean_k if mean_k > 0 else None,
+                            "tile_deal": "vp_tile_owner: every world-th 8x8 tile of a row, rows shifted by a hash of the row index"}
         if args.dump_image:
             import numpy as np
             np.save(args.dump_image, image.cpu().numpy())

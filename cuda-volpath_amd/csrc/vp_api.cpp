@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -83,18 +84,27 @@ struct State
     unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS;
     unsigned    blocks_per_cu = 6;  // resident 256-thread workgroups per CU (the register budget of each kernel decides how many really are)
     bool        use_lds_bounds = true;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    // launch timing: a ring of the last kMaxPendingEvents launches; older pairs are folded into the running sum
+    std::deque<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> event_pool;
+    double      timed_ms    = 0.0;   // folded launches
+    int         timed_n     = 0;     // launches counted (folded or pending or dropped)
+    // Per-sample staging per launch.  A launch ends with a tail in which only the deepest paths are still running (about
+    // 14 ms at 800x600 whatever the launch size), so launches should be long: 128 frames per launch (1 GiB) lose 9 % to
+    // tails, 1024 frames (8 GB) 1 %.  288 GB of HBM make that cheap; the cap is also held to a quarter of the free memory
+    // at allocation time.  VP_STAGE_MB overrides.
+    size_t      max_stage_bytes = (size_t)16 << 30;
     float       inv_model[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     std::string err;
 };
-State G;
+// The default context serves every thread that never called vp_ctx_set_current: the reference host (one scene, one device,
+// kernel.cu's file-scope statics) binds Part 1 and never sees a context.
+State                g_default;
+thread_local State*  t_current = nullptr;
+inline State& cur() { return t_current ? *t_current : g_default; }
+#define G cur()
+constexpr size_t kMaxPendingEvents = 64;
 
-// Per-sample staging per launch.  A launch ends with a tail in which only the deepest paths are still running
-// (about 14 ms at 800x600 whatever the launch size), so launches should be long: 128 frames per launch (1 GiB) lose
-// 9 % to tails, 1024 frames (8 GB) 1 %.  288 GB of HBM make that cheap; the cap is also held to a quarter of the free
-// memory at allocation time.  VP_STAGE_MB overrides.
-size_t kMaxStageBytes = (size_t)16 << 30;
 constexpr size_t kQueueWords = VP_NQUEUES * VP_QUEUE_STRIDE;  // queue heads of one launch
 
 int fail(int code, const char* fmt, ...)
@@ -117,12 +127,21 @@ int fail(int code, const char* fmt, ...)
     do                                                                                          \
     {                                                                                           \
         hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess) return fail(VP_E_NODEVICE, "%s -> %s", #expr, hipGetErrorString(e_)); \
+        if (e_ != hipSuccess)                                                                   \
+        {                                                                                       \
+            if (e_ == hipErrorOutOfMemory) (void)hipGetLastError(); /* not sticky: later calls may succeed */ \
+            return fail(e_ == hipErrorOutOfMemory ? VP_E_NOMEM : VP_E_NODEVICE, "%s -> %s", #expr, hipGetErrorString(e_)); \
+        }                                                                                       \
     } while (0)
 
 int ensure_device()
 {
-    if (G.dev_ready) return VP_OK;
+    if (G.dev_ready)
+    {
+        // another context of this process may have left a different device current on this thread
+        HIPCHK(hipSetDevice(G.device));
+        return VP_OK;
+    }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(VP_E_NODEVICE, "no HIP device visible");
     if (G.device >= n) return fail(VP_E_NODEVICE, "device %d out of range (%d visible)", G.device, n);
@@ -139,13 +158,29 @@ int ensure_device()
     HIPCHK(hipMemset(G.d_counters, 0, 16 * sizeof(unsigned long long)));
     G.S.sun_cos = 94.0f / sqrtf(94.0f * 94.0f + 0.45f * 0.45f);                    // kernel.cu:1263
     G.S.cam_z   = (float)(-1.0f / tan((double)54.43f * 0.00872664626));             // kernel.cu:1981-1985
-    // tuning knobs (performance only; results never depend on them)
-    if (const char* e = getenv("VP_WAIT_LANES")) G.wait_lanes = (unsigned)atoi(e);
-    if (const char* e = getenv("VP_WAIT_ITERS")) G.wait_iters = (unsigned)atoi(e);
-    if (const char* e = getenv("VP_STAGE_MB")) kMaxStageBytes = (size_t)atoi(e) << 20;
-    if (const char* e = getenv("VP_BLOCKS_PER_CU")) G.blocks_per_cu = (unsigned)atoi(e);
-    if (const char* e = getenv("VP_NO_LDS_BOUNDS")) G.use_lds_bounds = atoi(e) == 0;
-    if (const char* e = getenv("VP_LOOKAHEAD")) G.la_max = atoi(e);
+    // tuning knobs (performance only; results never depend on them).  Out-of-range or malformed values are ignored:
+    // wait_lanes = 0 would end the tracking loop before its first step (a persistent kernel that never finishes),
+    // blocks_per_cu = 0 is an empty grid, a negative VP_STAGE_MB a huge size_t.
+    auto knob = [](const char* name, long lo, long hi, long& out) {
+        const char* e = getenv(name);
+        if (!e || !*e) return false;
+        char* end = nullptr;
+        long  v   = strtol(e, &end, 10);
+        if (*end || v < lo || v > hi)
+        {
+            fprintf(stderr, "volpath_hip: ignoring %s=%s (allowed %ld..%ld)\n", name, e, lo, hi);
+            return false;
+        }
+        out = v;
+        return true;
+    };
+    long v;
+    if (knob("VP_WAIT_LANES", 1, 64, v)) G.wait_lanes = (unsigned)v;
+    if (knob("VP_WAIT_ITERS", VP_STEPS_PER_PASS, 1 << 20, v)) G.wait_iters = (unsigned)v;
+    if (knob("VP_STAGE_MB", 1, 256 << 10, v)) G.max_stage_bytes = (size_t)v << 20;
+    if (knob("VP_BLOCKS_PER_CU", 1, 8, v)) G.blocks_per_cu = (unsigned)v;
+    if (knob("VP_NO_LDS_BOUNDS", 0, 1, v)) G.use_lds_bounds = v == 0;
+    if (knob("VP_LOOKAHEAD", 0, 4096, v)) G.la_max = (int)v;
     G.dev_ready = true;
     return VP_OK;
 }
@@ -171,7 +206,20 @@ int free_volume()
     return VP_OK;
 }
 
+int do_init_volume_(const void* h_volume, vp_extent ext, bool quantized, const vp_float3* bmin, const vp_float3* bmax);
 int do_init_volume(const void* h_volume, vp_extent ext, bool quantized, const vp_float3* bmin, const vp_float3* bmax)
+{
+    int rc = do_init_volume_(h_volume, ext, quantized, bmin, bmax);
+    if (rc)
+    {
+        // a failed upload leaves no half-built scene behind (free_volume keeps the error text of the failure)
+        std::string why = G.err;
+        (void)free_volume();
+        G.err = why;
+    }
+    return rc;
+}
+int do_init_volume_(const void* h_volume, vp_extent ext, bool quantized, const vp_float3* bmin, const vp_float3* bmax)
 {
     G.epoch++;  // staged look-ahead frames no longer describe this scene ...
     (void)la_quiesce();  // ... and batches in flight must not see device buffers change under them
@@ -201,9 +249,16 @@ int do_init_volume(const void* h_volume, vp_extent ext, bool quantized, const vp
     }
     for (int a = 0; a < 3; a++) S.linv[a] = 1.0f / (S.bmax[a] - S.bmin[a]);  // kernel.cu:313
     G.quant = quantized;
-    // volume -> packed neighbourhood cells
+    // volume -> packed neighbourhood cells.  The three scratch buffers belong to a guard: every early return frees them.
+    struct Scratch
+    {
+        void* p[3] = {nullptr, nullptr, nullptr};
+        ~Scratch() { for (void* q : p) if (q) (void)hipFree(q); }
+    } tmp;
+    void*& d_raw = tmp.p[0];
+    void*& d_ta  = tmp.p[1];
+    void*& d_tb  = tmp.p[2];
     const size_t vbytes = n * (quantized ? 1 : 4);
-    void*        d_raw  = nullptr;
     HIPCHK(hipMalloc(&d_raw, vbytes));
     HIPCHK(hipMemcpyAsync(d_raw, h_volume, vbytes, hipMemcpyHostToDevice, G.stream));
     HIPCHK(hipMalloc(&G.d_cells, n * (quantized ? 8 : 32)));
@@ -219,7 +274,6 @@ int do_init_volume(const void* h_volume, vp_extent ext, bool quantized, const vp
     S.bnx = (nx + G.brick - 1) / G.brick; S.bny = (ny + G.brick - 1) / G.brick; S.bnz = (nz + G.brick - 1) / G.brick;
     const size_t nb    = (size_t)S.bnx * S.bny * S.bnz;
     const size_t psize = quantized ? 2 : 8;
-    void *d_ta = nullptr, *d_tb = nullptr;
     HIPCHK(hipMalloc(&d_ta, n * psize));
     HIPCHK(hipMalloc(&d_tb, n * psize));
     HIPCHK(hipMalloc(&G.d_bounds, nb * psize + 16));  // padded: the LDS stage copies whole 16-byte words
@@ -236,10 +290,7 @@ int do_init_volume(const void* h_volume, vp_extent ext, bool quantized, const vp
         S.bounds_f32 = (const float*)G.d_bounds;
         S.cells_f32  = (const float*)G.d_cells;
     }
-    HIPCHK(hipStreamSynchronize(G.stream));  // caller may free h_volume on return (host.cpp:1343)
-    HIPCHK(hipFree(d_raw));
-    HIPCHK(hipFree(d_ta));
-    HIPCHK(hipFree(d_tb));
+    HIPCHK(hipStreamSynchronize(G.stream));  // caller may free h_volume on return (host.cpp:1343); scratch freed by the guard
     S.linear      = G.linear ? 1 : 0;
     G.have_volume = true;
     return VP_OK;
@@ -314,12 +365,53 @@ int build_env_tables()
     return VP_OK;
 }
 
+// an event from the pool, or a new one; nullptr if the runtime cannot create one (the launch then goes untimed)
 hipEvent_t get_event()
 {
     if (!G.event_pool.empty()) { hipEvent_t e = G.event_pool.back(); G.event_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return e;
+}
+void put_event(hipEvent_t e) { if (e) G.event_pool.push_back(e); }
+// keep at most kMaxPendingEvents launch pairs: fold the oldest into the running sum (its elapsed time if the pair
+// has completed; a launch this old that has not is counted without a time rather than waited for)
+void trim_events()
+{
+    while (G.events.size() > kMaxPendingEvents)
+    {
+        auto  ev = G.events.front();
+        float ms = 0.0f;
+        G.events.pop_front();
+        if (hipEventQuery(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) G.timed_ms += ms;
+        else (void)hipGetLastError();
+        put_event(ev.first); put_event(ev.second);
+    }
+}
+
+// the tile slots of this context's shard (include/volpath.h vp_tile_owner; vp_kernels.h owned_tile)
+struct Shard { unsigned tiles_x, tiles_y, tiles_per_row, owned; size_t per_frame; };
+Shard shard_of(const Param* p)
+{
+    Shard s;
+    s.tiles_x       = (p->width + 7) / 8;
+    s.tiles_y       = (p->height + 7) / 8;
+    s.tiles_per_row = (s.tiles_x + G.world - 1) / G.world;
+    s.owned         = s.tiles_per_row * s.tiles_y;
+    s.per_frame     = (size_t)s.owned * 64;
+    return s;
+}
+// frames of per_frame samples one staged launch may hold: the configured cap, a quarter of the memory that is free
+// now (plus what the target buffer already holds), and the 32-bit sample queue
+size_t stage_frames_cap(size_t per_frame, size_t have_bytes)
+{
+    size_t cap = G.max_stage_bytes;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap = std::min(cap, std::max(have_bytes, (free_b + have_bytes) / 4));
+    else (void)hipGetLastError();
+    size_t f = cap / (per_frame * sizeof(float4));
+    f = std::min<size_t>(f, 0xfffffff0u / per_frame);
+    return std::max<size_t>(f, 1);
 }
 
 // where a render launch goes: the caller's stream with the shared staging buffer, or a look-ahead slot
@@ -345,31 +437,21 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     LaunchDev L = {};
     static_assert(sizeof(ParamDev) == sizeof(Param) && sizeof(Param) == 44, "Param layout (param.h:4-12)");
     memcpy(&L.P, p, sizeof(Param));
-    L.tiles_x = (p->width + 7) / 8;
-    L.tiles_y = (p->height + 7) / 8;
-    unsigned ntiles = L.tiles_x * L.tiles_y;
+    const Shard sh = shard_of(p);
+    L.tiles_x = sh.tiles_x; L.tiles_y = sh.tiles_y; L.tiles_per_row = sh.tiles_per_row;
     L.rank = G.rank; L.world = G.world;
-    L.ntiles_owned = ntiles > G.rank ? (ntiles - G.rank + G.world - 1) / G.world : 0;
+    L.ntiles_owned = sh.owned;
     L.out = (float4*)d_out;
     L.queue = T.queue;
     L.counters = G.count ? G.d_counters : nullptr;
     L.key0 = G.key0; L.key1 = G.key1;
     L.wait_lanes = G.wait_lanes; L.wait_iters = G.wait_iters;
     if (L.ntiles_owned == 0) return VP_OK;
-    const size_t per_frame = (size_t)L.ntiles_owned * 64;
-    // the owned tiles (row-major) split into VP_NQUEUES bands of whole tiles
+    const size_t per_frame = sh.per_frame;
+    if (0xfffffff0u / per_frame < 1) return fail(VP_E_ARG, "image too large for the 32-bit sample queue");
+    // the owned tile slots (row-major) split into VP_NQUEUES bands of whole tiles
     for (unsigned q = 0; q <= VP_NQUEUES; q++) L.q_start[q] = (unsigned)((unsigned long long)L.ntiles_owned * q / VP_NQUEUES) * 64u;
-    size_t stage_cap = kMaxStageBytes;
-    if (nframes > 1 && (size_t)nframes * per_frame * sizeof(float4) > *T.stage_bytes)
-    {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) stage_cap = std::min(stage_cap, std::max(*T.stage_bytes, (free_b + *T.stage_bytes) / 4));
-    }
-    size_t max_f = stage_cap / (per_frame * sizeof(float4));
-    if (max_f < 1) max_f = 1;
-    size_t cap_items = 0xfffffff0u / per_frame;
-    if (cap_items < 1) return fail(VP_E_ARG, "image too large for the 32-bit sample queue");
-    if (max_f > cap_items) max_f = cap_items;
+    size_t max_f = (nframes > 1 || stage_only) ? stage_frames_cap(per_frame, *T.stage_bytes) : 1;
     SceneDev S = G.S;
     S.linear   = G.linear ? 1 : 0;
     for (int done = 0; done < nframes;)
@@ -387,7 +469,16 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                 HIPCHK(hipStreamSynchronize(T.stream));
                 HIPCHK(hipStreamSynchronize(G.stream));  // add-kernels of earlier frames may still read the old buffer
                 if (*T.stage) HIPCHK(hipFree(*T.stage));
-                HIPCHK(hipMalloc((void**)T.stage, need));
+                *T.stage = nullptr; *T.stage_bytes = 0;
+                if (hipMalloc((void**)T.stage, need) != hipSuccess)
+                {
+                    // another allocator took the memory since it was measured: a smaller batch renders the same bits
+                    (void)hipGetLastError();
+                    *T.stage = nullptr;
+                    if (stage_only) return fail(VP_E_NOMEM, "no memory for a look-ahead batch of %d frames", f);
+                    if (f > 1) { max_f = (size_t)std::max(f / 2, 1); continue; }
+                    return fail(VP_E_NOMEM, "no memory for one staged frame (%zu bytes)", need);
+                }
                 *T.stage_bytes = need;
             }
             L.stage = *T.stage;
@@ -404,11 +495,14 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         unsigned cap    = (unsigned)G.num_cu * (lds_bounds ? 2u : G.blocks_per_cu);
         if (blocks > cap) blocks = cap;
         hipEvent_t e0 = get_event(), e1 = get_event();
-        HIPCHK(hipEventRecord(e0, T.stream));
+        bool timed = e0 && e1 && hipEventRecord(e0, T.stream) == hipSuccess;
         launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, G.trk, (int)blocks, T.stream);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(e1, T.stream));
-        G.events.emplace_back(e0, e1);
+        hipError_t le = hipGetLastError();
+        timed = timed && le == hipSuccess && hipEventRecord(e1, T.stream) == hipSuccess;
+        G.timed_n++;
+        if (timed) { G.events.emplace_back(e0, e1); trim_events(); }
+        else { put_event(e0); put_event(e1); }
+        if (le != hipSuccess) return fail(VP_E_NODEVICE, "render launch -> %s", hipGetErrorString(le));
         if (L.stage && !stage_only)
         {
             launch_reduce(L, T.stream);
@@ -456,9 +550,10 @@ int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, c
     s.valid = false;
     // after everything queued on the caller's stream: uploads the scene depends on, and add-kernels still reading this slot
     hipEvent_t ev = get_event();
+    if (!ev) return fail(VP_E_NODEVICE, "hipEventCreate failed");
     HIPCHK(hipEventRecord(ev, G.stream));
     HIPCHK(hipStreamWaitEvent(s.stream, ev, 0));
-    G.event_pool.push_back(ev);
+    put_event(ev);
     const Target t = {s.stream, &s.buf, &s.bytes, G.d_queue + kQueueWords * (si + 1)};
     int rc = do_render(d_out, first, n, p, true, &t);
     if (rc) return rc;
@@ -466,15 +561,10 @@ int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, c
     s.valid = true; s.first = first; s.count = n; s.key = key;
     return VP_OK;
 }
-int la_limit(int first, int n, size_t per_frame)
+int la_limit(int first, int n, size_t per_frame, size_t have_bytes)
 {
     if (G.est == VP_EST_DECOMP && !G.S.opacity) n = first <= 10 ? std::min(n, 11 - first) : 0;  // quirk Q5 needs the opacity volume
-    if (per_frame && n > 0)
-    {
-        size_t fit = kMaxStageBytes / (per_frame * sizeof(float4));
-        fit = std::min<size_t>(fit, 0xfffffff0u / per_frame);
-        n = (int)std::min<size_t>((size_t)n, std::max<size_t>(fit, 1));
-    }
+    if (per_frame && n > 0) n = (int)std::min<size_t>((size_t)n, stage_frames_cap(per_frame, have_bytes));
     return n;
 }
 int serve_frame(vp_float4* d_out, int frame, const Param* p)
@@ -484,9 +574,8 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
     if (rc) return rc;
     std::vector<unsigned char> key;
     render_key(p, key);
-    const unsigned tiles_x = (p->width + 7) / 8, tiles_y = (p->height + 7) / 8, ntiles = tiles_x * tiles_y;
-    const unsigned owned = ntiles > G.rank ? (ntiles - G.rank + G.world - 1) / G.world : 0;
-    const size_t per_frame = (size_t)owned * 64;
+    const Shard sh = shard_of(p);
+    const size_t per_frame = sh.per_frame;
     for (int si = 0; si < 2 && d_out && per_frame; si++)
     {
         auto& s = G.la[si];
@@ -498,14 +587,15 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
         const int next = s.first + s.count;
         if (frame == s.first && s.count >= G.la_max && !(o.valid && o.key == key && o.first == next))
         {
-            int n = la_limit(next, G.la_max, per_frame);
+            int n = la_limit(next, G.la_max, per_frame, o.bytes);
             if (n > 1 && la_render_slot(si ^ 1, d_out, next, n, p, key)) G.la[si ^ 1].valid = false;  // best effort
         }
         // hit: add the staged frame once its batch is rendered
         HIPCHK(hipStreamWaitEvent(G.stream, s.done, 0));
         LaunchDev L = {};
         memcpy(&L.P, p, sizeof(Param));
-        L.tiles_x = tiles_x; L.tiles_y = tiles_y; L.rank = G.rank; L.world = G.world; L.ntiles_owned = owned;
+        L.tiles_x = sh.tiles_x; L.tiles_y = sh.tiles_y; L.tiles_per_row = sh.tiles_per_row;
+        L.rank = G.rank; L.world = G.world; L.ntiles_owned = sh.owned;
         L.out = (float4*)d_out;
         L.stage = s.buf + (size_t)(frame - s.first) * per_frame;
         L.nframes = 1;
@@ -517,12 +607,18 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
     // miss: how far ahead?  only when this call continues the previous one
     const bool same = key == G.la_key;
     int n = (same && frame == G.la_last + 1) ? std::min(std::max(G.la_prev_n, 1) * 2, G.la_max) : 1;
-    if (n > 1) n = std::max(la_limit(frame, n, per_frame), 1);
+    if (n > 1) n = std::max(la_limit(frame, n, per_frame, G.la[0].bytes), 1);
     G.la_key = key; G.la_last = frame; G.la_prev_n = n;
     G.la[0].valid = G.la[1].valid = false;
     if (n <= 1 || !per_frame || !d_out) return do_render(d_out, frame, 1, p);
-    rc = la_render_slot(0, d_out, frame, n, p, key);
-    if (rc) return rc;
+    // The look-ahead is an optimisation the caller never asked for: if the batch cannot be rendered (no memory for its
+    // staging slot, a stream that cannot be created) this frame is rendered alone, exactly as without look-ahead, and
+    // the batch size starts over.
+    if (la_render_slot(0, d_out, frame, n, p, key))
+    {
+        G.la[0].valid = false; G.la_prev_n = 0;
+        return do_render(d_out, frame, 1, p);
+    }
     return serve_frame(d_out, frame, p);  // now a hit (which also starts the following batch once n is full size)
 }
 }  // namespace
@@ -627,9 +723,90 @@ int vp_device_count(void)
 }
 int vp_set_device(int device)
 {
-    if (G.dev_ready && device != G.device) return fail(VP_E_STATE, "device already initialised as %d", G.device);
+    if (G.dev_ready && device != G.device)
+        return fail(VP_E_STATE, "this context is bound to device %d; use vp_ctx_create(%d) for another GPU", G.device, device);
     G.device = device;
     return ensure_device();
+}
+
+// ---- contexts
+struct vp_ctx { State st; };
+vp_ctx* vp_ctx_create(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n)
+    {
+        fail(VP_E_NODEVICE, "vp_ctx_create: device %d not visible (%d devices)", device, n);
+        return nullptr;
+    }
+    vp_ctx* c = new vp_ctx();
+    c->st.device = device;
+    State* prev = t_current;
+    t_current   = &c->st;
+    int rc      = ensure_device();
+    std::string why = c->st.err;
+    t_current   = prev;
+    if (rc)
+    {
+        delete c;
+        fail(rc, "vp_ctx_create(%d): %s", device, why.c_str());
+        return nullptr;
+    }
+    return c;
+}
+int vp_ctx_set_current(vp_ctx* ctx)
+{
+    t_current = ctx ? &ctx->st : nullptr;
+    if (G.dev_ready) HIPCHK(hipSetDevice(G.device));
+    return VP_OK;
+}
+vp_ctx* vp_ctx_get_current(void) { return t_current ? reinterpret_cast<vp_ctx*>(t_current) : nullptr; }
+int vp_ctx_device(void) { return G.device; }
+int vp_ctx_destroy(vp_ctx* ctx)
+{
+    if (!ctx) return VP_OK;
+    State* prev = t_current;
+    t_current   = &ctx->st;
+    State& D    = ctx->st;
+    int rc = VP_OK;
+    if (D.dev_ready)
+    {
+        (void)hipSetDevice(D.device);
+        (void)hipStreamSynchronize(D.stream);
+        (void)la_quiesce();
+        rc = free_volume();
+        free_envmap();
+        for (auto& sl : D.la)
+        {
+            if (sl.buf) (void)hipFree(sl.buf);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        }
+        for (auto& ev : D.events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        for (auto e : D.event_pool) (void)hipEventDestroy(e);
+        if (D.d_stage) (void)hipFree(D.d_stage);
+        if (D.d_queue) (void)hipFree(D.d_queue);
+        if (D.d_counters) (void)hipFree(D.d_counters);
+        if (D.own_stream) (void)hipStreamDestroy(D.own_stream);
+    }
+    t_current = (prev == &ctx->st) ? nullptr : prev;
+    delete ctx;
+    if (G.dev_ready) (void)hipSetDevice(G.device);
+    return rc;
+}
+int vp_accumulate(vp_float4* dst, const vp_float4* src, size_t n)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!dst || !src) return fail(VP_E_ARG, "vp_accumulate: null pointer");
+    if (n) launch_accumulate((float4*)dst, (const float4*)src, n, G.stream);
+    HIPCHK(hipGetLastError());
+    return VP_OK;
+}
+int vp_tile_owner(unsigned tx, unsigned ty, int world)
+{
+    if (world < 1) return -1;
+    return (int)((tx + vp::tile_row_shift(ty, (unsigned)world)) % (unsigned)world);
 }
 int vp_set_stream(void* s)
 {
@@ -639,6 +816,11 @@ int vp_set_stream(void* s)
     if (la_quiesce()) return VP_E_NODEVICE;
     G.stream = s ? (hipStream_t)s : G.own_stream;
     return VP_OK;
+}
+void* vp_get_stream(void)
+{
+    if (ensure_device()) return nullptr;
+    return (void*)G.stream;
 }
 int vp_synchronize(void)
 {
@@ -734,7 +916,7 @@ int vp_render_time_ms(double* total_ms, int* launches, int reset)
     HIPCHK(hipStreamSynchronize(G.stream));
     for (auto& sl : G.la)  // look-ahead batches still in flight are launches too
         if (sl.stream) HIPCHK(hipStreamSynchronize(sl.stream));
-    double tot = 0;
+    double tot = G.timed_ms;
     for (auto& ev : G.events)
     {
         float ms = 0;
@@ -742,11 +924,12 @@ int vp_render_time_ms(double* total_ms, int* launches, int reset)
         tot += ms;
     }
     if (total_ms) *total_ms = tot;
-    if (launches) *launches = (int)G.events.size();
+    if (launches) *launches = G.timed_n;
     if (reset)
     {
-        for (auto& ev : G.events) { G.event_pool.push_back(ev.first); G.event_pool.push_back(ev.second); }
+        for (auto& ev : G.events) { put_event(ev.first); put_event(ev.second); }
         G.events.clear();
+        G.timed_ms = 0.0; G.timed_n = 0;
     }
     return VP_OK;
 }
@@ -820,6 +1003,77 @@ int vp_test_sample_density(const float* pos_xyz, float* out, int n)
     return VP_OK;
 }
 
+// device buffers of one test call: freed on every return path
+struct DevArrays
+{
+    std::vector<void*> p;
+    ~DevArrays() { for (void* q : p) (void)hipFree(q); }
+    void* get(size_t bytes)
+    {
+        void* q = nullptr;
+        if (hipMalloc(&q, bytes ? bytes : 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        p.push_back(q);
+        return q;
+    }
+};
+int vp_test_hg(const float* g, const float* r0, const float* r1, const float* normal_xyz, const float* cos_query, float* dir_xyz, float* eval, int n)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n <= 0) return VP_OK;
+    DevArrays D;
+    const size_t b = (size_t)n * 4;
+    float *dg = (float*)D.get(b), *d0 = (float*)D.get(b), *d1 = (float*)D.get(b), *dn = (float*)D.get(3 * b), *dc = (float*)D.get(b);
+    float *dd = (float*)D.get(3 * b), *de = (float*)D.get(b);
+    if (!dg || !d0 || !d1 || !dn || !dc || !dd || !de) return fail(VP_E_NOMEM, "vp_test_hg: no device memory");
+    HIPCHK(hipMemcpy(dg, g, b, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d0, r0, b, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d1, r1, b, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dn, normal_xyz, 3 * b, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dc, cos_query, b, hipMemcpyHostToDevice));
+    launch_test_hg(dg, d0, d1, dn, dc, dd, de, n, G.stream);
+    HIPCHK(hipStreamSynchronize(G.stream));
+    HIPCHK(hipMemcpy(dir_xyz, dd, 3 * b, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(eval, de, b, hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+int vp_test_intersect_box(const float* origin_xyz, const float* dir_xyz, int* hit, float* tnear, float* tfar, int n)
+{
+    if (!G.have_volume) return fail(VP_E_STATE, "no volume (the box comes from init_cuda)");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n <= 0) return VP_OK;
+    DevArrays D;
+    const size_t b = (size_t)n * 4;
+    float *dor = (float*)D.get(3 * b), *ddi = (float*)D.get(3 * b), *dtn = (float*)D.get(b), *dtf = (float*)D.get(b);
+    int*   dh  = (int*)D.get(b);
+    if (!dor || !ddi || !dtn || !dtf || !dh) return fail(VP_E_NOMEM, "vp_test_intersect_box: no device memory");
+    HIPCHK(hipMemcpy(dor, origin_xyz, 3 * b, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ddi, dir_xyz, 3 * b, hipMemcpyHostToDevice));
+    launch_test_box(G.S, dor, ddi, dh, dtn, dtf, n, G.stream);
+    HIPCHK(hipStreamSynchronize(G.stream));
+    HIPCHK(hipMemcpy(hit, dh, b, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tnear, dtn, b, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tfar, dtf, b, hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+int vp_test_eval_envmap(const float* dir_xyz, float* rgb, int n)
+{
+    if (!G.have_env) return fail(VP_E_STATE, "no environment map");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n <= 0) return VP_OK;
+    DevArrays D;
+    const size_t b = (size_t)n * 12;
+    float *dd = (float*)D.get(b), *dq = (float*)D.get(b);
+    if (!dd || !dq) return fail(VP_E_NOMEM, "vp_test_eval_envmap: no device memory");
+    HIPCHK(hipMemcpy(dd, dir_xyz, b, hipMemcpyHostToDevice));
+    launch_test_env(G.S, dd, dq, n, G.stream);
+    HIPCHK(hipStreamSynchronize(G.stream));
+    HIPCHK(hipMemcpy(rgb, dq, b, hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+
 int vp_julia_voxelize(int n, unsigned char* host_out)
 {
     int rc = ensure_device();
@@ -840,7 +1094,14 @@ void* vp_malloc(size_t bytes)
 {
     if (ensure_device()) return nullptr;
     void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) { fail(VP_E_NODEVICE, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+    {
+        (void)hipGetLastError();
+        fail(e == hipErrorOutOfMemory ? VP_E_NOMEM : VP_E_NODEVICE, "hipMalloc(%zu) -> %s (%s)", bytes, hipGetErrorString(e),
+             e == hipErrorOutOfMemory ? "VP_E_NOMEM" : "VP_E_NODEVICE");
+        return nullptr;
+    }
     return p;
 }
 int vp_free(void* p) { HIPCHK(hipFree(p)); return VP_OK; }

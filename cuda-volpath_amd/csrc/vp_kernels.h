@@ -34,6 +34,17 @@
 
 namespace vp
 {
+// Pixel-tile deal (include/volpath.h vp_tile_owner): tile (tx, ty) belongs to rank (tx + tile_row_shift(ty)) % world, i.e.
+// within a tile row every world-th tile, rows shifted against each other by a hash of the row index.  Slot `ot` of a rank
+// is its (ot % tiles_per_row)-th tile of row ot / tiles_per_row; slots past the row's end (tx >= tiles_x) are padding.
+__host__ __device__ inline unsigned tile_row_shift(unsigned ty, unsigned world) { return ((ty * 0x9E3779B1u) >> 15) % world; }
+__host__ __device__ inline void owned_tile(unsigned ot, unsigned tiles_per_row, unsigned rank, unsigned world, unsigned& tx, unsigned& ty)
+{
+    ty         = ot / tiles_per_row;
+    unsigned j = ot - ty * tiles_per_row;
+    tx         = j * world + (rank + world - tile_row_shift(ty, world)) % world;
+}
+
 // same values as the VP_EST_* / VP_RNG_* enums of include/volpath.h
 constexpr int EST_GLOBAL = 0, EST_DECOMP = 1, EST_BOUNDED = 2;
 constexpr int RNG_SAMPLERH = 0, RNG_PHILOX = 1;
@@ -44,7 +55,8 @@ struct LaunchDev
     ParamDev P;
     int      frame0, nframes;
     unsigned tiles_x, tiles_y;
-    unsigned ntiles_owned, rank, world;
+    unsigned tiles_per_row;  // owned tile slots per tile row: ceil(tiles_x / world); slots beyond the row's end are padding
+    unsigned ntiles_owned, rank, world;  // ntiles_owned = tiles_per_row * tiles_y (padding included)
     unsigned total_items;  // nframes * ntiles_owned * 64
     float4*  out;          // W*H accumulator (caller-owned)
     float4*  stage;        // [nframes][ntiles_owned*64] per-sample results, or null = accumulate directly
@@ -68,6 +80,10 @@ void launch_build_bounds(const void* d_vol, bool quant, void* d_out, void* d_tmp
 void launch_julia(unsigned char* grid, int n, hipStream_t st);
 void launch_scale(float4* dst, const float4* src, int size, float s, hipStream_t st);
 void launch_gamma(float4* dst, const float4* src, int size, float s, float inv_gamma, hipStream_t st);
+void launch_accumulate(float4* dst, const float4* src, size_t n, hipStream_t st);
+void launch_test_hg(const float* g, const float* r0, const float* r1, const float* nrm, const float* cosq, float* dir, float* ev, int n, hipStream_t st);
+void launch_test_box(const SceneDev& S, const float* o, const float* d, int* hit, float* tn, float* tf, int n, hipStream_t st);
+void launch_test_env(const SceneDev& S, const float* d, float* out, int n, hipStream_t st);
 void launch_test_math(int which, const float* in, float* out, int n, hipStream_t st);
 void launch_test_rng(int mode, unsigned x, unsigned y, unsigned f, unsigned k0, unsigned k1, int n, float* out, hipStream_t st);
 void launch_test_density(const SceneDev& S, bool quant, const float* pos, float* out, int n, hipStream_t st);

@@ -376,8 +376,8 @@ void render_k(SceneDev S, LaunchDev L)
                             unsigned fl  = item / per_frame;
                             unsigned rem = item - fl * per_frame;
                             unsigned ot  = rem >> 6, w = rem & 63u;
-                            unsigned t   = ot * L.world + L.rank;
-                            unsigned ty  = t / L.tiles_x, tx = t - ty * L.tiles_x;
+                            unsigned tx, ty;
+                            owned_tile(ot, L.tiles_per_row, L.rank, L.world, tx, ty);
                             px    = tx * 8u + (w & 7u);
                             py    = ty * 8u + (w >> 3);
                             frame = L.frame0 + (int)fl;
@@ -658,8 +658,8 @@ __global__ __launch_bounds__(256) void reduce_stage_k(LaunchDev L)
     unsigned slot      = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= per_frame) return;
     unsigned ot = slot >> 6, w = slot & 63u;
-    unsigned t  = ot * L.world + L.rank;
-    unsigned ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+    unsigned tx, ty;
+    owned_tile(ot, L.tiles_per_row, L.rank, L.world, tx, ty);
     unsigned px = tx * 8u + (w & 7u), py = ty * 8u + (w >> 3);
     if (px >= L.P.width || py >= L.P.height) return;
     size_t idx = (size_t)px + (size_t)py * L.P.width;
@@ -839,7 +839,43 @@ __global__ void julia_k(unsigned char* grid, int n)
     grid[idx] = iter > 27 ? 255 : 0;
 }
 
+// dst += src (float4): sums per-shard accumulators of several contexts on one device
+__global__ void accumulate_k(float4* dst, const float4* src, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = dst[i], b = src[i];
+    dst[i]   = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
 // ---- test kernels
+// the phase-function block of the integrator (kernel.cu:2301-2303 with :557-598) and HGPhaseFunction::evaluate (:600-603)
+__global__ void test_hg_k(const float* g, const float* r0, const float* r1, const float* nrm, const float* cosq, float* dir, float* ev, int n)
+{
+    int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i >= n) return;
+    Frame fr(f3{nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]});
+    f3    d = normalize(fr.to_world(hg_sample_local(g[i], r0[i], r1[i])));
+    dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
+    ev[i] = hg_eval(g[i], cosq[i]);
+}
+// intersectBox kernel.cu:654-680 against the current volume box
+__global__ void test_box_k(SceneDev S, const float* o, const float* d, int* hit, float* tn, float* tf, int n)
+{
+    int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i >= n) return;
+    float a, b;
+    hit[i] = intersect_box(f3{o[3 * i], o[3 * i + 1], o[3 * i + 2]}, f3{d[3 * i], d[3 * i + 1], d[3 * i + 2]}, S, a, b) ? 1 : 0;
+    tn[i] = a; tf[i] = b;
+}
+// eval_envmap kernel.cu:956-973
+__global__ void test_env_k(SceneDev S, const float* d, float* out, int n)
+{
+    int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i >= n) return;
+    f3 c = eval_envmap(S, f3{d[3 * i], d[3 * i + 1], d[3 * i + 2]});
+    out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+}
 __global__ void test_math_k(int which, const float* in, float* out, int n)
 {
     int i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -1069,6 +1105,22 @@ void launch_scale(float4* dst, const float4* src, int size, float s, hipStream_t
 void launch_gamma(float4* dst, const float4* src, int size, float s, float inv_gamma, hipStream_t st)
 {
     hipLaunchKernelGGL(gamma_k, dim3((size + 255) / 256), dim3(256), 0, st, dst, src, size, s, inv_gamma);
+}
+void launch_accumulate(float4* dst, const float4* src, size_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(accumulate_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n);
+}
+void launch_test_hg(const float* g, const float* r0, const float* r1, const float* nrm, const float* cosq, float* dir, float* ev, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(test_hg_k, dim3((n + 255) / 256), dim3(256), 0, st, g, r0, r1, nrm, cosq, dir, ev, n);
+}
+void launch_test_box(const SceneDev& S, const float* o, const float* d, int* hit, float* tn, float* tf, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(test_box_k, dim3((n + 255) / 256), dim3(256), 0, st, S, o, d, hit, tn, tf, n);
+}
+void launch_test_env(const SceneDev& S, const float* d, float* out, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(test_env_k, dim3((n + 255) / 256), dim3(256), 0, st, S, d, out, n);
 }
 void launch_test_math(int which, const float* in, float* out, int n, hipStream_t st)
 {

@@ -7,10 +7,35 @@
 // Reference call sites: sky_tungsten.cpp:433-502 (Skydome), hosek/ArHosekSkyModel.cpp:147-304, :402-561,
 // :653-815 (model), host.cpp:276-333 (bake).  Arithmetic is double inside the model, float around it,
 // as in the reference.
+//
+// The model evaluated here is the Hosek-Wilkie sky-dome / solar-radiance model; its evaluation routines (e.g. the solar
+// polynomial below) necessarily follow the structure of the authors' reference implementation, which the upstream project
+// vendors under the following licence (src/sunsky/hosek/ArHosekSkyModel.cpp:1-30):
+//
+//   Copyright (c) 2012 - 2013, Lukas Hosek and Alexander Wilkie.  All rights reserved.
+//
+//   Redistribution and use in source and binary forms, with or without modification, are permitted provided that the
+//   following conditions are met:
+//     * Redistributions of source code must retain the above copyright notice, this list of conditions and the following
+//       disclaimer.
+//     * Redistributions in binary form must reproduce the above copyright notice, this list of conditions and the following
+//       disclaimer in the documentation and/or other materials provided with the distribution.
+//     * None of the names of the contributors may be used to endorse or promote products derived from this software without
+//       specific prior written permission.
+//
+//   THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS" AND ANY EXPRESS OR IMPLIED WARRANTIES,
+//   INCLUDING, BUT NOT LIMITED TO, THE IMPLIED WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A PARTICULAR PURPOSE ARE
+//   DISCLAIMED.  IN NO EVENT SHALL THE COPYRIGHT HOLDERS BE LIABLE FOR ANY DIRECT, INDIRECT, INCIDENTAL, SPECIAL, EXEMPLARY,
+//   OR CONSEQUENTIAL DAMAGES (INCLUDING, BUT NOT LIMITED TO, PROCUREMENT OF SUBSTITUTE GOODS OR SERVICES; LOSS OF USE, DATA,
+//   OR PROFITS; OR BUSINESS INTERRUPTION) HOWEVER CAUSED AND ON ANY THEORY OF LIABILITY, WHETHER IN CONTRACT, STRICT
+//   LIABILITY, OR TORT (INCLUDING NEGLIGENCE OR OTHERWISE) ARISING IN ANY WAY OUT OF THE USE OF THIS SOFTWARE, EVEN IF
+//   ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
 #include "sky.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "data/sky_tables.inc"
 
@@ -137,7 +162,14 @@ void Skydome::prepare()
     if (_prepared) return;
     _sun = sunDirection();
     float elev = std::asin(clampf(_sun.y, -1.0f, 1.0f));
-    hosek_alienworld_init(_state, elev, _intensity, _temperature, _turbidity, 0.2f);  // sky_tungsten.cpp:449-451
+    // sky_tungsten.cpp:449-451.  Skydome's turbidity is the constant 2 of the reference (its constructor, no setter); should
+    // that ever change, a sky silently baked from an uninitialised state would be worse than stopping here.
+    if (!hosek_alienworld_init(_state, elev, _intensity, _temperature, _turbidity, 0.2f))
+    {
+        fprintf(stderr, "Skydome: no Hosek-Wilkie coefficients for turbidity %g (only the turbidity-2 rows are carried, data/sky_tables.inc)\n",
+                (double)_turbidity);
+        abort();
+    }
     _prepared = true;
 }
 

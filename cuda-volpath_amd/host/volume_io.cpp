@@ -9,10 +9,18 @@ void* loadRawFile(const char* filename, size_t size)
 {
     FILE* fp = fopen(filename, "rb");
     if (!fp) { fprintf(stderr, "Error opening file '%s'\n", filename); return nullptr; }
-    void*  data = malloc(size);
-    size_t got  = fread(data, 1, size, fp);
+    void* data = malloc(std::max<size_t>(size, 1));
+    if (!data) { fclose(fp); fprintf(stderr, "Out of memory reading '%s' (%zu bytes)\n", filename, size); return nullptr; }
+    size_t got = fread(data, 1, size, fp);
     fclose(fp);
     printf("Read '%s', %zu bytes\n", filename, got);
+    if (got != size)
+    {
+        // the reference returns the buffer with an uninitialised tail here (host.cpp:904-911); a short file is an error
+        fprintf(stderr, "File '%s' is truncated: %zu of %zu bytes\n", filename, got, size);
+        free(data);
+        return nullptr;
+    }
     return data;
 }
 
@@ -46,11 +54,20 @@ void* loadBinaryFile(const char* filename, int& width, int& height, int& depth, 
         return nullptr;
     }
     float* dataf = reinterpret_cast<float*>(malloc(sizeof(float) * std::max<size_t>(total, 1)));
-    size_t got   = fread(dataf, sizeof(float), total, fp);
+    if (!dataf) { fclose(fp); fprintf(stderr, "Out of memory reading '%s'\n", filename); return nullptr; }
+    size_t got = fread(dataf, sizeof(float), total, fp);
     fclose(fp);
     printf("Read '%s', %zu bytes\n", filename, got);
+    if (got != total)
+    {
+        // a truncated dump would otherwise be quantised and uploaded with an uninitialised tail
+        fprintf(stderr, "File '%s' is truncated: %zu of %zu voxels\n", filename, got, total);
+        free(dataf);
+        return nullptr;
+    }
     if (!quantized) return dataf;
     VolumeType* data = reinterpret_cast<VolumeType*>(malloc(std::max<size_t>(total, 1)));
+    if (!data) { free(dataf); fprintf(stderr, "Out of memory reading '%s'\n", filename); return nullptr; }
     quantize_unit(dataf, total, data);
     free(dataf);
     return data;
@@ -69,6 +86,8 @@ bool dump_dense_volume(const char* filename, const float* data, int nx, int ny, 
 }
 
 #ifndef VOLPATH_WITH_OPENVDB
+// host/vdb_openvdb.cpp holds the OpenVDB -> dense conversion; the Makefile builds it (and defines VOLPATH_WITH_OPENVDB) only
+// where <openvdb/openvdb.h> exists.  The reference does not vendor OpenVDB either (vdbloader/CMakeLists.txt:2).
 float* load_vdb(char* filename, int&, int&, int&, float&, float&)
 {
     fprintf(stderr, "load_vdb('%s'): built without OpenVDB; convert the grid to the dense .bin dump and use loadBinaryFile\n", filename);

@@ -14,8 +14,10 @@ void* loadBinaryFile(const char* filename, int& width, int& height, int& depth, 
 // host.cpp:968-1019: load_vdb + uchar(max(0,v)/max_value*255) quantiser
 void* loadVdbFile(const char* filename, int& width, int& height, int& depth, bool quantized = true);
 // vdbloader/load_vdb.h: first FloatGrid -> dense float array over the active bbox (+ dims and value range).
-// Built against OpenVDB when VOLPATH_WITH_OPENVDB is defined; otherwise it reports the missing
-// dependency and returns nullptr (OpenVDB is not vendored by the reference either).
+// host/vdb_openvdb.cpp implements it against OpenVDB; the Makefile compiles that file (defining VOLPATH_WITH_OPENVDB) only
+// where <openvdb/openvdb.h> is found -- NOT in the image this project is developed in, where that file has therefore never
+// been compiled.  Without it load_vdb reports the missing dependency and returns nullptr (the reference does not vendor
+// OpenVDB either).
 float* load_vdb(char* filename, int& width, int& height, int& depth, float& min_value, float& max_value);
 // the dump format of vdbloader/load_vdb.cpp:52-69 (Volume::dump): int32 nx,ny,nz then nx*ny*nz float32, x fastest
 bool dump_dense_volume(const char* filename, const float* data, int nx, int ny, int nz);

@@ -22,10 +22,12 @@ TRACK_SPECTRAL, TRACK_SCALAR, TRACK_MULTI_CHANNEL = 0, 1, 2
 PART1_SYMBOLS = ["init_cuda", "set_texture_filter_mode", "free_cuda_buffers", "precompute_opacity", "init_envmap",
                  "free_envmap", "set_sun", "copy_inv_view_matrix", "copy_inv_model_matrix", "init_rng", "free_rng",
                  "render_kernel", "scale", "gamma_correct"]
-PART2_SYMBOLS = ["vp_last_error", "vp_version", "vp_device_count", "vp_set_device", "vp_set_stream", "vp_synchronize",
+PART2_SYMBOLS = ["vp_last_error", "vp_version", "vp_device_count", "vp_set_device", "vp_set_stream", "vp_get_stream", "vp_synchronize",
                  "vp_set_estimator", "vp_set_rng", "vp_set_envmap_sampling", "vp_get_env_tables", "vp_set_lookahead", "vp_set_tracking", "vp_set_bound_brick", "vp_set_shard", "vp_render_frames",
                  "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity",
-                 "vp_julia_voxelize", "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_malloc", "vp_free", "vp_memset",
+                 "vp_julia_voxelize", "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_test_hg", "vp_test_intersect_box",
+                 "vp_test_eval_envmap", "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_current", "vp_ctx_get_current", "vp_ctx_device",
+                 "vp_accumulate", "vp_tile_owner", "vp_malloc", "vp_free", "vp_memset",
                  "vp_upload", "vp_download"]
 
 
@@ -78,6 +80,7 @@ def lib():
         L.vp_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.vp_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.vp_set_stream.argtypes = [C.c_void_p]
+        L.vp_get_stream.restype = C.c_void_p
         L.vp_set_rng.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
         L.vp_get_env_tables.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.vp_render_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Param)]
@@ -89,6 +92,16 @@ def lib():
         L.vp_test_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.vp_test_rng.argtypes = [C.c_int] + [C.c_uint32] * 5 + [C.c_int, C.c_void_p]
         L.vp_test_sample_density.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.vp_test_hg.argtypes = [C.c_void_p] * 7 + [C.c_int]
+        L.vp_test_intersect_box.argtypes = [C.c_void_p] * 5 + [C.c_int]
+        L.vp_test_eval_envmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.vp_ctx_create.restype = C.c_void_p
+        L.vp_ctx_create.argtypes = [C.c_int]
+        L.vp_ctx_destroy.argtypes = [C.c_void_p]
+        L.vp_ctx_set_current.argtypes = [C.c_void_p]
+        L.vp_ctx_get_current.restype = C.c_void_p
+        L.vp_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.vp_tile_owner.argtypes = [C.c_uint, C.c_uint, C.c_int]
         L.init_cuda.argtypes = [C.c_void_p, Extent, C.c_bool, C.POINTER(Float3), C.POINTER(Float3)]
         L.init_cuda.restype = None
         L.set_texture_filter_mode.argtypes = [C.c_bool]
@@ -323,6 +336,66 @@ def test_sample_density(pos):
     out = np.empty(pos.shape[0], np.float32)
     _chk(lib().vp_test_sample_density(_p(pos), _p(out), pos.shape[0]))
     return out
+
+
+def test_hg(g, r0, r1, normal, cos_query):
+    """(direction after HGPhaseFunction::sample through Frame(normal), HGPhaseFunction::evaluate(cos_query)) on the device"""
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    g, r0, r1, normal, cos_query = f(g), f(r0), f(r1), f(normal), f(cos_query)
+    n = g.size
+    d = np.empty((n, 3), np.float32)
+    e = np.empty(n, np.float32)
+    _chk(lib().vp_test_hg(_p(g), _p(r0), _p(r1), _p(normal), _p(cos_query), _p(d), _p(e), n))
+    return d, e
+
+
+def test_intersect_box(origin, direction):
+    o = np.ascontiguousarray(origin, np.float32)
+    d = np.ascontiguousarray(direction, np.float32)
+    n = o.shape[0]
+    hit = np.empty(n, np.int32)
+    tn = np.empty(n, np.float32)
+    tf = np.empty(n, np.float32)
+    _chk(lib().vp_test_intersect_box(_p(o), _p(d), _p(hit), _p(tn), _p(tf), n))
+    return hit.astype(bool), tn, tf
+
+
+def test_eval_envmap(direction):
+    d = np.ascontiguousarray(direction, np.float32)
+    out = np.empty_like(d)
+    _chk(lib().vp_test_eval_envmap(_p(d), _p(out), d.shape[0]))
+    return out
+
+
+class Context:
+    """One scene on one GPU (include/volpath.h "Contexts").  `with ctx:` makes it the calling thread's current context."""
+
+    def __init__(self, device=0):
+        self.h = lib().vp_ctx_create(device)
+        if not self.h:
+            raise VolpathError(lib().vp_last_error().decode())
+        self._prev = []
+
+    def __enter__(self):
+        self._prev.append(lib().vp_ctx_get_current())
+        _chk(lib().vp_ctx_set_current(self.h))
+        return self
+
+    def __exit__(self, *exc):
+        _chk(lib().vp_ctx_set_current(self._prev.pop()))
+
+    def destroy(self):
+        if self.h:
+            _chk(lib().vp_ctx_destroy(self.h))
+            self.h = None
+
+
+def accumulate(dst_ptr, src_ptr, n_float4):
+    _chk(lib().vp_accumulate(dst_ptr, src_ptr, n_float4))
+
+
+def tile_owner(tx, ty, world):
+    return lib().vp_tile_owner(tx, ty, world)
 
 
 def julia_volume(n):

@@ -98,7 +98,8 @@ enum
     VP_E_NODEVICE  = -1, /* no gfx950 device / HIP runtime error */
     VP_E_STATE     = -2, /* call order (e.g. render before init_cuda / init_envmap) */
     VP_E_ARG       = -3,
-    VP_E_NOOPACITY = -4  /* frame > 10 with the decomposition estimator needs precompute_opacity */
+    VP_E_NOOPACITY = -4, /* frame > 10 with the decomposition estimator needs precompute_opacity */
+    VP_E_NOMEM     = -5  /* device memory exhausted (hipErrorOutOfMemory) */
 };
 
 enum { VP_EST_GLOBAL = 0, /* __d_render, kernel.cu:1285-1591: global majorant (BASELINE config 2) */
@@ -111,8 +112,25 @@ enum { VP_RNG_SAMPLERH = 0, /* src/sampler.h bit-compatible streams (parity mode
 const char* vp_last_error(void);
 const char* vp_version(void);
 int  vp_device_count(void);
-int  vp_set_device(int device);       /* before any other call; default 0 */
+int  vp_set_device(int device);       /* device of the CURRENT context; before its first GPU call; default 0 */
+
+/* Contexts.  The reference keeps its scene in file-scope statics and __constant__ symbols: one scene, one device per process
+ * (kernel.cu:148-151, :621-629; cudaSetDevice(0) src/denoiser.cpp:94-97).  Here all of that state lives in a context.  Every
+ * entry point of this header -- Part 1 included -- acts on the calling thread's current context; a thread that never set one
+ * uses the process-wide default context, so the reference host binds the 14 Part-1 symbols unchanged.  One context per GPU
+ * gives a single-process multi-GPU host (host/main.cpp --gpus N: N contexts, pixel tiles dealt by vp_set_shard, one RCCL
+ * reduce).  A context is not thread-safe; different contexts may be driven from different threads. */
+typedef struct vp_ctx vp_ctx;
+vp_ctx* vp_ctx_create(int device);         /* NULL on failure (vp_last_error of the current context says why) */
+int     vp_ctx_destroy(vp_ctx* ctx);       /* frees its device memory; the current context becomes the default one if it was ctx */
+int     vp_ctx_set_current(vp_ctx* ctx);   /* NULL = the default context */
+vp_ctx* vp_ctx_get_current(void);          /* NULL while the default context is current */
+int     vp_ctx_device(void);               /* device index of the current context */
+/* dst[i] += src[i] for n float4 on the current context's stream (device pointers of ITS device): sums per-shard accumulators
+ * where no collective is available (several contexts on one GPU) */
+int     vp_accumulate(vp_float4* dst, const vp_float4* src, size_t n);
 int  vp_set_stream(void* hip_stream); /* hipStream_t to launch on; NULL = library-owned stream */
+void* vp_get_stream(void);            /* the hipStream_t the current context launches on (for a collective queued behind a render) */
 int  vp_synchronize(void);
 
 int vp_set_estimator(int est);                         /* default VP_EST_DECOMP */
@@ -139,8 +157,11 @@ int vp_set_envmap_sampling(int mode);                  /* default VP_ENV_PASSIVE
 int vp_get_env_tables(float* cdf_y, float* cdf_x, float* pdfnorm_alt);
 /* brick edge (power of two, 1 = the reference's per-voxel table) used by the NEXT init_cuda */
 int vp_set_bound_brick(int brick);
-/* pixel-tile sharding: this process renders the 8x8 tiles t with t % world == rank */
+/* Pixel-tile sharding: this context renders the 8x8 pixel tiles (tx, ty) with vp_tile_owner(tx, ty, world) == rank: within
+ * a tile row every world-th tile, the rows shifted against each other by a hash of the row index, so that neither columns
+ * nor rows nor diagonals of the image belong to one rank whatever tiles_x % world is. */
 int vp_set_shard(int rank, int world);
+int vp_tile_owner(unsigned tx, unsigned ty, int world);
 
 /* Adds frames [first_frame, first_frame + n_frames) into d_output[width*height] (device).
  * Per pixel the samples are added in frame order, so the result equals n_frames successive
@@ -163,7 +184,8 @@ int vp_enable_counters(int on);
 int vp_read_counters(vp_counters* out, int reset); /* synchronises */
 
 /* kernel time of the render launches since the last reset, measured with HIP events on the
- * launch stream; synchronises */
+ * launch stream; synchronises.  At most 64 launches are kept pending: older ones are folded into the running sum when
+ * their events have completed, so a host that never asks does not accumulate events. */
 int vp_render_time_ms(double* total_ms, int* launches, int reset);
 
 /* the derived tables, for tests: bound table dims/brick and a device->host copy */
@@ -174,6 +196,13 @@ int vp_get_opacity(float* dst, size_t count);
 int vp_test_math(int which, const float* in, float* out, int n);
 int vp_test_rng(int mode, uint32_t x, uint32_t y, uint32_t frame, uint32_t k0, uint32_t k1, int n, float* out);
 int vp_test_sample_density(const float* pos_xyz, float* out, int n);
+/* component hooks for known-answer tests against float64 closed forms (no oracle involved):
+ * HGPhaseFunction::sample through Frame (kernel.cu:557-598, the phase-function block :2301-2303) and ::evaluate (:600-603);
+ * intersectBox (kernel.cu:654-680) against the current volume box; eval_envmap (kernel.cu:956-973, dir_to_uv :882-895) */
+int vp_test_hg(const float* g, const float* r0, const float* r1, const float* normal_xyz, const float* cos_query, float* dir_xyz,
+               float* eval, int n);
+int vp_test_intersect_box(const float* origin_xyz, const float* dir_xyz, int* hit, float* tnear, float* tfar, int n);
+int vp_test_eval_envmap(const float* dir_xyz, float* rgb, int n);
 
 /* The procedural Julia-set volume of the reference (FractalJuliaSet, kernel.cu:84-140) voxelised at
  * texel centres over [-1,1]^3 to an n^3 uchar grid (0 / 255), x fastest; written to HOST memory so it

@@ -1,0 +1,263 @@
+"""BASELINE configs 4 / 5 on the GPU: ~512^3 dense grid, chromatic medium (preset #1), 1280x720, decomposition tracking.
+
+The WDAS cloud itself (and OpenVDB) is not available offline, so the workload is the FLAGGED SYNTHETIC STAND-IN `c4s`
+(volpath/scene.py): same grid size, medium, image and estimator.  At full size the checks are size-independent properties
+(batched == frame by frame, shard union == whole for 2 and 8 ranks -- config 5's partition --, finite / non-negative,
+decomposition vs global-majorant convergence); the data path real cloud data takes -- dense float dump -> loadBinaryFile ->
+init_cuda (src/volumeRender.cpp:915-965, vdbloader/load_vdb.cpp:52-69) -- is compared bit for bit with the oracle at
+reduced size on a non-cubic, float, chromatic volume, for the library and for the C++ driver.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def c4s(vp):
+    from volpath import scene as vscene
+    P, info = vscene.setup("c4s", rng_mode=vp.RNG_PHILOX, last_frame=64)
+    assert (P.width, P.height) == (1280, 720) and info["n"] == 512 and info["chromatic"]
+    return P, info
+
+
+def test_c4s_batched_equals_frame_by_frame_and_shards_add_up(vp, c4s):
+    P, info = c4s
+    W, H = P.width, P.height
+    vp.set_estimator(vp.EST_DECOMP)
+    vp.set_shard(0, 1)
+    a, b = vp.DeviceBuffer(W, H), vp.DeviceBuffer(W, H)
+    frames = range(9, 13)                                   # across the frame-11 estimator switch (quirk Q5)
+    vp.render_frames(a.ptr, frames[0], len(frames), P)      # one launch, staged, added in frame order
+    for f in frames:
+        vp.render_kernel(b.ptr, f, P)                       # the reference's call pattern
+    whole = a.download()
+    assert np.array_equal(whole, b.download())
+    assert np.isfinite(whole).all() and (whole >= 0).all()
+    assert (whole[..., 3] > 0).mean() > 0.05
+    b.free()
+    from volpath import dist as vd
+    for world in (2, 8):                                    # 8 ranks at 160 tiles per row: BASELINE config 5's partition
+        tot = np.zeros_like(whole)
+        for r in range(world):
+            a.reset()
+            vp.set_shard(r, world)
+            vp.render_frames(a.ptr, frames[0], len(frames), P)
+            part = a.download()
+            assert not part[~vd.owned_mask(r, world, W, H)].any()      # a rank writes its own tiles only
+            tot += part
+        assert np.array_equal(tot, whole), world
+    vp.set_shard(0, 1)
+    a.free()
+
+
+def test_c4s_decomposition_and_global_majorant_converge(vp, c4s):
+    """the live kernel (16^3 bricks in LDS) and the global-majorant kernel estimate the same image on the 512^3 chromatic
+    workload: 64 spp each; 40x40 block means within 3 % of the image mean + 4 standard errors, image means within 1.5 %
+    (the bound is the optical-depth table's bias, quirk Q5, as at 256^3)"""
+    P, info = c4s
+    W, H, frames = P.width, P.height, 64
+    imgs = {}
+    for est in (vp.EST_DECOMP, vp.EST_GLOBAL):
+        vp.set_estimator(est)
+        vp.set_rng(vp.RNG_PHILOX, (77, est))
+        buf = vp.DeviceBuffer(W, H)
+        vp.render_frames(buf.ptr, 0, frames, P)
+        imgs[est] = buf.download()[..., :3].astype(np.float64) / frames
+        buf.free()
+    vp.set_estimator(vp.EST_DECOMP)
+    a, b = imgs[vp.EST_DECOMP], imgs[vp.EST_GLOBAL]
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert np.allclose(a.mean((0, 1)), b.mean((0, 1)), rtol=1.5e-2), (a.mean((0, 1)), b.mean((0, 1)))
+    blocks = lambda im: im.reshape(18, 40, 32, 40, 3).mean(axis=(1, 3))
+    spread = lambda im: im.reshape(18, 40, 32, 40, 3).std(axis=(1, 3)) / np.sqrt(1600.0)
+    tol = 0.03 * b.mean() + 4.0 * np.sqrt(spread(a) ** 2 + spread(b) ** 2)
+    assert (np.abs(blocks(a) - blocks(b)) > tol).mean() < 0.01
+    # chromatic medium: the three channels really differ
+    assert abs(a[..., 0].mean() / a[..., 2].mean() - 1) > 0.02
+
+
+def _cloudlet(shape=(20, 28, 36), seed=12):
+    """a small non-cubic float density field with empty space, values partly outside [0,1] (the dump is clamped on load)"""
+    rng = np.random.default_rng(seed)
+    nz, ny, nx = shape
+    z, y, x = np.mgrid[0:nz, 0:ny, 0:nx].astype(np.float32)
+    r = np.sqrt(((x - nx / 2) / nx) ** 2 + ((y - ny / 2) / ny) ** 2 + ((z - nz / 2) / nz) ** 2)
+    v = np.clip(1.5 - 4.0 * r, -0.2, 1.3) * (0.5 + 0.5 * rng.random(shape, dtype=np.float32))
+    v[r > 0.33] = 0
+    return v.astype(np.float32)
+
+
+@pytest.mark.parametrize("quantized", [True, False])
+def test_dense_dump_ingest_path_is_bit_exact(vp, oracle, tmp_path, quantized):
+    """dump_dense_volume -> loadBinaryFile -> init_cuda, chromatic preset #1, decomposition estimator: == oracle.
+    quantized = the path of BASELINE config 4 (uchar(clamp(v,0,1)*255), host.cpp:955); float = the reference's
+    `quantized = false` branch of the same loader."""
+    from volpath import host
+    W, H = 64, 48
+    vol = _cloudlet()
+    path = str(tmp_path / "cloudlet.bin")
+    assert host.dump_dense(path, vol)
+    grid = host.load_binary(path, quantized=quantized)
+    assert grid.shape == vol.shape and grid.dtype == (np.uint8 if quantized else np.float32)
+    if quantized:
+        assert np.array_equal(grid, (np.clip(vol, 0, 1) * np.float32(255)).astype(np.uint8))
+    else:
+        assert np.array_equal(grid, vol)
+        grid = np.clip(grid, 0, 1)            # the float texture path wants densities in [0,1] like the uchar one
+    nz, ny, nx = grid.shape
+    box = ((-1.0, -ny / nx, -nz / nx), (1.0, ny / nx, nz / nx))            # host.cpp:1336-1339
+    env = scenes.synthetic_env()
+    osc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, brick=1, estimator=oracle.EST_DECOMP,
+                             rng_mode=oracle.RNG_PHILOX, seed=(3, 4), box=box)
+    oP, vP = oracle.default_param(W, H, density=120.0), vp.make_param(W, H, density=120.0)
+    oracle.mat(oP, *scenes.PRESET1)
+    vp.mat(vP, *scenes.PRESET1)
+    vp.init_volume(grid, box=box, brick=1, linear=True)
+    vp.init_envmap(env)
+    vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+    vp.set_camera()
+    vp.set_estimator(vp.EST_DECOMP)
+    vp.set_rng(vp.RNG_PHILOX, (3, 4))
+    vp.set_shard(0, 1)
+    ref = None
+    for f in range(4):
+        ref, _ = osc.render_frame(oP, f, ref)
+    buf = vp.DeviceBuffer(W, H)
+    vp.render_frames(buf.ptr, 0, 4, vP)
+    got = buf.download()
+    buf.free()
+    assert (ref[..., 3] > 0).mean() > 0.05
+    assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+
+
+def test_cli_bin_ingest_matches_oracle_and_two_contexts_match_one(vp, oracle, tmp_path):
+    """volpath_render --bin (C++ host: loadBinaryFile, box from the dims, Hosek bake, preset, reference entry points, gamma,
+    PPM) end to end == oracle; and --gpus 2 on one device (two contexts, disjoint tile shards, on-device sum -- the
+    single-process multi-GPU host with the RCCL reduce replaced by vp_accumulate because both contexts share the GPU)
+    writes the same file byte for byte."""
+    import ctypes as C
+    from volpath import host
+    exe = os.path.join(ROOT, "cuda-volpath_amd", "volpath_render")
+    vol = _cloudlet()
+    path = str(tmp_path / "cloudlet.bin")
+    assert host.dump_dense(path, vol)
+    W, H, spp = 72, 40, 5
+    common = ["--bin", path, "--size", str(W), str(H), "--spp", str(spp), "--preset", "0", "--density", "150", "--rng", "philox"]
+    out1, out2, out3 = (str(tmp_path / n) for n in ("one.ppm", "two.ppm", "three.hdr"))
+    r = subprocess.run([exe] + common + ["--out", out1], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r2 = subprocess.run([exe] + common + ["--gpus", "2", "--devices", "0,0", "--out", out2], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert "2 ranks (shared device" in r2.stdout and "balance max/mean" in r2.stdout
+    assert open(out1, "rb").read() == open(out2, "rb").read()
+    r3 = subprocess.run([exe] + common + ["--gpus", "3", "--devices", "0,0,0", "--batch", "2", "--out", out3], capture_output=True, text=True)
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    # the oracle on the same inputs
+    grid = (np.clip(vol, 0, 1) * np.float32(255)).astype(np.uint8)
+    nz, ny, nx = grid.shape
+    box = ((-1.0, -ny / nx, -nz / nx), (1.0, ny / nx, nz / nx))
+    env, sun_dir, sun_power = host.bake_sunsky(0.5, 0.2)
+    osc = oracle.OracleScene(grid, env, sun_dir, sun_power, inv_view=host.camera_matrix(), rng_mode=oracle.RNG_PHILOX,
+                             seed=(0x9E3779B9, 0x85EBCA6B), box=box)
+    oP = oracle.default_param(W, H, density=150.0)
+    oracle.mat(oP, *scenes.PRESET1)
+    acc = None
+    for f in range(spp):
+        acc, _ = osc.render_frame(oP, f, acc)
+    disp = np.empty_like(acc)
+    oracle.lib().vpo_gamma_correct(disp.ctypes.data_as(C.c_void_p), acc.ctypes.data_as(C.c_void_p), W * H, 1.0 / spp, 2.2)
+    expect = (np.minimum(disp[::-1, :, :3], 1.0) * np.float32(255)).astype(np.uint8)
+    raw = open(out1, "rb").read()
+    head = f"P6\n{W} {H}\n255\n".encode()
+    assert raw.startswith(head)
+    assert np.array_equal(np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3), expect)
+    assert (acc[..., 3] > 0).mean() > 0.03
+
+
+def test_two_contexts_on_one_device_sum_to_the_one_context_image(vp, oracle):
+    """explicit contexts.  Two contexts on device 0 hold their own scene copies and render disjoint tile
+    shards concurrently; their on-device sum (vp_accumulate) is bit-identical to the default context's image, and the
+    default context -- the one the reference's 14 entry points act on -- is untouched by them."""
+    W, H = 120, 56           # 15 tiles per row: not a multiple of the world size
+    grid = oracle.julia(32)
+    env = scenes.synthetic_env()
+
+    def scene(rank, world):
+        vp.init_volume(grid, brick=1, linear=True)
+        vp.init_envmap(env)
+        vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+        vp.set_camera()
+        vp.set_estimator(vp.EST_DECOMP)
+        vp.set_rng(vp.RNG_PHILOX, (8, 1))
+        vp.set_shard(rank, world)
+
+    scene(0, 1)
+    P = vp.make_param(W, H)
+    one = vp.DeviceBuffer(W, H)
+    vp.render_frames(one.ptr, 0, 6, P)
+    want = one.download()
+    ctxs = [vp.Context(0), vp.Context(0)]
+    bufs = []
+    for r, c in enumerate(ctxs):
+        with c:
+            assert vp.lib().vp_ctx_device() == 0
+            scene(r, 2)
+            bufs.append(vp.DeviceBuffer(W, H))
+            vp.render_frames(bufs[r].ptr, 0, 6, P)          # asynchronous: both contexts' launches are in flight together
+    with ctxs[1]:
+        vp.synchronize()
+        part1 = bufs[1].download()
+    with ctxs[0]:
+        vp.accumulate(bufs[0].ptr, bufs[1].ptr, W * H)
+        got = bufs[0].download()
+    assert part1.any() and not np.array_equal(part1, want)
+    assert np.array_equal(got, want)
+    # the default context still renders its own (unsharded) scene
+    one.reset()
+    vp.render_frames(one.ptr, 0, 6, P)
+    assert np.array_equal(one.download(), want)
+    for r, c in enumerate(ctxs):
+        with c:
+            bufs[r].free()
+    for c in ctxs:
+        c.destroy()
+    one.free()
+
+
+def test_event_ring_stays_bounded_and_oom_is_reported(vp, oracle):
+    """a host that renders forever and never asks for timings must not accumulate events; a failed device
+    allocation is VP_E_NOMEM (-5), not "no device"."""
+    W, H = 32, 24
+    vp.init_volume(oracle.julia(16), brick=1)
+    vp.init_envmap(scenes.synthetic_env())
+    vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+    vp.set_camera()
+    vp.set_estimator(vp.EST_GLOBAL)
+    vp.set_shard(0, 1)
+    vp.set_lookahead(0)
+    try:
+        P = vp.make_param(W, H)
+        buf = vp.DeviceBuffer(W, H)
+        vp.render_time_ms(reset=True)
+        for f in range(300):
+            vp.render_kernel(buf.ptr, f, P)
+        ms, n = vp.render_time_ms(reset=True)
+        assert n == 300 and ms > 0                       # all 300 launches counted, although only 64 pairs are kept pending
+        buf.free()
+    finally:
+        vp.set_lookahead(64)
+    L = vp.lib()
+    assert L.vp_malloc(1 << 50) is None                  # 1 PiB
+    assert b"VP_E_NOMEM" in L.vp_last_error() or b"memory" in L.vp_last_error().lower()
+    # the library is still usable afterwards (an out-of-memory error is not sticky)
+    buf = vp.DeviceBuffer(W, H)
+    vp.render_frames(buf.ptr, 0, 2, vp.make_param(W, H))
+    assert np.isfinite(buf.download()).all()
+    buf.free()

@@ -12,27 +12,56 @@ import scenes
 
 def test_tile_partition_is_disjoint_and_complete():
     from volpath import dist as vd
-    for (w, h) in ((64, 48), (70, 45), (800, 600)):
+    for (w, h) in ((64, 48), (70, 45), (800, 600), (1280, 720)):
         for world in (1, 2, 3, 8):
             om = vd.owner_map(world, w, h)
-            assert om.shape == (h, w) and om.min() == 0 and om.max() == min(world - 1, om.max())
+            assert om.shape == (h, w) and om.min() == 0 and om.max() == world - 1
             cover = sum(vd.owned_mask(r, world, w, h).astype(int) for r in range(world))
             assert np.all(cover == 1)
             tx, ty = vd.tile_grid(w, h)
             assert sum(len(vd.owned_tiles(r, world, w, h)) for r in range(world)) == tx * ty
 
 
-def test_round_robin_tiles_balance_the_julia_image():
-    """weight = scatters+1 per pixel; round-robin 8x8 tiles keep max/mean near 1 (bands: 2.36)."""
+def test_tile_deal_matches_the_library_and_is_not_stripes():
+    """dist.py restates vp_tile_owner (the mapping render_k uses); at 1280x720 x 8 ranks -- 160 tiles per row, where
+    `tile % 8` would hand each rank vertical 8-pixel stripes -- no rank owns a whole tile column or two equal rows."""
+    import volpath
+    from volpath import dist as vd
+    for (w, h, world) in ((1280, 720, 8), (800, 600, 8), (70, 45, 3), (64, 48, 2)):
+        m = vd.tile_owner_map(world, w, h)
+        ty, tx = m.shape
+        lib = np.array([[volpath.tile_owner(i, j, world) for i in range(tx)] for j in range(0, ty, 7)])
+        assert np.array_equal(lib, m[::7])
+        # within a row: every world-th tile
+        assert np.all((m[:, 1:] - m[:, :-1]) % world == 1)
+    m = vd.tile_owner_map(8, 1280, 720)
+    assert all(len(set(m[:, c])) == 8 for c in range(m.shape[1]))           # every column sees every rank
+    shifts = vd.row_shift(np.arange(m.shape[0]), 8)
+    assert np.bincount(shifts.astype(int), minlength=8).min() >= m.shape[0] // 8 - 4   # row shifts cover all residues evenly
+
+
+def test_tile_deal_balances_the_julia_image():
+    """weight = scatters+1 per pixel (the oracle's heat channel); contiguous bands give max/mean 2.36.
+    The deal keeps it <= 1.05 at 1280x720 over 8 ranks (BASELINE config 5) and at 800x600."""
     import oracle_lib as O
     from volpath import dist as vd
     g = O.julia(64)
     sc = O.OracleScene(g, scenes.synthetic_env(), scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
-    P = O.default_param(200, 150)
-    acc, _ = sc.render_frame(P, 0)
-    wgt = acc[..., 3] + 1
-    loads = np.array([wgt[vd.owned_mask(r, 8, 200, 150)].sum() for r in range(8)])
-    assert loads.max() / loads.mean() < 1.25
+    for (w, h) in ((1280, 720), (800, 600)):
+        P = O.default_param(w // 4, h // 4)  # heat map at quarter resolution, one tile = 2x2 of its pixels
+        acc = None
+        for f in range(4):
+            acc, _ = sc.render_frame(P, f, acc)
+        wgt = np.repeat(np.repeat(acc[..., 3] + 4, 4, axis=0), 4, axis=1)[:h, :w]
+        for world in (2, 4, 8):
+            b, per = vd.balance(wgt, world)
+            assert b <= 1.05, (w, h, world, b, per)
+        # the degenerate deal this replaces: tile % 8 at 160 tiles per row = vertical stripes
+        tx, ty = vd.tile_grid(w, h)
+        t = (np.arange(h)[:, None] // 8) * tx + (np.arange(w)[None, :] // 8)
+        old = np.array([wgt[(t % 8) == r].sum() for r in range(8)])
+        if w == 1280:
+            assert old.max() / old.mean() > b  # stripes are worse than the hashed rows
 
 
 def _worker(rank, world, port, q):
