@@ -78,9 +78,15 @@ def test_hg_sample_and_evaluate_match_closed_forms(vp):
     b = np.cross(N, t)
     w = t * (np.cos(phi) * st)[:, None] + b * (np.sin(phi) * st)[:, None] + N * ct[:, None]
     w /= np.linalg.norm(w, axis=1, keepdims=True)
-    # tolerance: 2e-5 absolute per component (binary32 with <= 3-ulp sin/cos; the frame amplifies by < 4)
+    # tolerance: 2e-5 absolute per component (binary32 with <= 3-ulp sin/cos; the frame amplifies by < 4), plus the
+    # conditioning of the formula itself next to the pole: 1 + g^2 - f^2 cancels, so binary32 leaves cos(theta) with an
+    # absolute error of a few 1e-7 (times 0.5/|g|), and sin(theta) = sqrt(1 - cos^2) turns an error e of cos(theta) ~ 1
+    # into sqrt(sin^2 + 2e) - sin
     near_axis = np.abs(np.abs(N[:, 0]) - 0.1) < 1e-6
-    assert np.abs(d - w)[~near_axis].max() < 2e-5
+    e_cos = 4e-7 * np.maximum(1.0, 0.5 / np.maximum(np.abs(G), 1e-3))
+    tol = 2e-5 + np.sqrt(st * st + 2 * e_cos) - st
+    assert np.all((np.abs(d - w) < tol[:, None])[~near_axis])
+    assert np.median(tol) < 3e-5
     assert np.abs(np.linalg.norm(d, axis=1) - 1).max() < 1e-6
     # Q1: with |g| > 1e-6 the sampled direction never points into the back hemisphere of the incoming direction
     cos_out = (d.astype(np.float64) * N).sum(1)
@@ -88,8 +94,12 @@ def test_hg_sample_and_evaluate_match_closed_forms(vp):
     assert (np.abs(cos_out[(np.abs(G) > 1e-6)]) < 2e-6).sum() > 50      # ... and the clamp is really hit
     assert cos_out[np.abs(G) <= 1e-6].min() < -0.5                       # the isotropic branch does sample backwards
     # evaluate: (1 - g^2) / (4 pi (1 + g^2 - 2 g cos)^1.5), 1e-5 relative
-    want = (1 - G * G) / (4 * PI * (1 + G * G - 2 * G * cq.astype(np.float64)) ** 1.5)
-    assert np.abs(ev / want - 1).max() < 1e-5
+    # 1e-5 relative, plus the cancellation in x = 1 + g^2 - 2 g cos for a forward peak (g = 0.99, cos ~ 1: x ~ 1e-4):
+    # three binary32 roundings of magnitude ~2 (4e-7 absolute) enter x^1.5 as 1.5 * 4e-7 / x
+    x = 1 + G * G - 2 * G * cq.astype(np.float64)
+    want = (1 - G * G) / (4 * PI * x ** 1.5)
+    assert np.all(np.abs(ev / want - 1) < 1e-5 + 6e-7 / x)
+    assert np.median(6e-7 / x) < 2e-6
 
 
 def test_intersect_box_matches_float64_slab_test(vp):
