@@ -81,9 +81,14 @@ struct State
     unsigned*   d_queue       = nullptr;
     unsigned long long* d_counters = nullptr;
     bool        count       = false;
-    unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS;
+    unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS, setup_lanes = VP_SETUP_LANES;
     unsigned    blocks_per_cu = 6;  // resident 256-thread workgroups per CU (the register budget of each kernel decides how many really are)
     bool        use_lds_bounds = true;
+    // where the restart crawl in front of the volume ends, per pixel (crawl_table_k); rebuilt when what it depends on changes
+    bool        use_crawl_table = true;
+    float4*     d_crawl     = nullptr;
+    size_t      crawl_bytes = 0;
+    std::vector<unsigned char> crawl_key;
     // launch timing: a ring of the last kMaxPendingEvents launches; older pairs are folded into the running sum
     std::deque<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> event_pool;
@@ -106,6 +111,7 @@ inline State& cur() { return t_current ? *t_current : g_default; }
 constexpr size_t kMaxPendingEvents = 64;
 
 constexpr size_t kQueueWords = VP_NQUEUES * VP_QUEUE_STRIDE;  // queue heads of one launch
+constexpr size_t kCounterWords = 48;  // 6 work counters, 6 loop statistics, 11 x (wave, lane) block tallies from word 16
 
 int fail(int code, const char* fmt, ...)
 {
@@ -154,8 +160,8 @@ int ensure_device()
     HIPCHK(hipStreamCreateWithFlags(&G.own_stream, hipStreamNonBlocking));
     if (!G.stream) G.stream = G.own_stream;
     HIPCHK(hipMalloc((void**)&G.d_queue, 3 * kQueueWords * sizeof(unsigned)));  // caller's stream + two look-ahead slots
-    HIPCHK(hipMalloc((void**)&G.d_counters, 16 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(G.d_counters, 0, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void**)&G.d_counters, kCounterWords * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(G.d_counters, 0, kCounterWords * sizeof(unsigned long long)));
     G.S.sun_cos = 94.0f / sqrtf(94.0f * 94.0f + 0.45f * 0.45f);                    // kernel.cu:1263
     G.S.cam_z   = (float)(-1.0f / tan((double)54.43f * 0.00872664626));             // kernel.cu:1981-1985
     // tuning knobs (performance only; results never depend on them).  Out-of-range or malformed values are ignored:
@@ -177,9 +183,11 @@ int ensure_device()
     long v;
     if (knob("VP_WAIT_LANES", 1, 64, v)) G.wait_lanes = (unsigned)v;
     if (knob("VP_WAIT_ITERS", VP_STEPS_PER_PASS, 1 << 20, v)) G.wait_iters = (unsigned)v;
+    if (knob("VP_SETUP_LANES", 1, 64, v)) G.setup_lanes = (unsigned)v;
     if (knob("VP_STAGE_MB", 1, 256 << 10, v)) G.max_stage_bytes = (size_t)v << 20;
     if (knob("VP_BLOCKS_PER_CU", 1, 8, v)) G.blocks_per_cu = (unsigned)v;
     if (knob("VP_NO_LDS_BOUNDS", 0, 1, v)) G.use_lds_bounds = v == 0;
+    if (knob("VP_NO_CRAWL_TABLE", 0, 1, v)) G.use_crawl_table = v == 0;
     if (knob("VP_LOOKAHEAD", 0, 4096, v)) G.la_max = (int)v;
     G.dev_ready = true;
     return VP_OK;
@@ -414,6 +422,49 @@ size_t stage_frames_cap(size_t per_frame, size_t have_bytes)
     return std::max<size_t>(f, 1);
 }
 
+// The per-pixel table of the restart crawl in front of the volume (vp_kernels.hip crawl_table_k) for the local-majorant
+// estimators.  It depends on the camera, the box, the bound table and the image size only -- not on the frame -- and is
+// rebuilt (one small kernel, synchronously: launches on other streams read it) when any of those changed.
+int ensure_crawl_table(const Param* p, const float4** out)
+{
+    *out = nullptr;
+    if (!G.use_crawl_table || G.est == VP_EST_GLOBAL) return VP_OK;
+    struct K { SceneDev S; unsigned w, h; int control, quant; unsigned long long epoch; };
+    std::vector<unsigned char> key(sizeof(K), 0);
+    K* k = reinterpret_cast<K*>(key.data());
+    memcpy(&k->S, &G.S, sizeof(SceneDev));
+    k->S.linear = 0; k->S.env = nullptr; k->S.opacity = nullptr; k->S.env_cdf_x = k->S.env_cdf_y = nullptr;  // not read by the walk
+    k->S.env_w = k->S.env_h = 0; k->S.env_pdfnorm_alt = 0.0f;
+    memset(k->S.sun_dir, 0, sizeof k->S.sun_dir); memset(k->S.sun_power, 0, sizeof k->S.sun_power); memset(k->S.sun_orig, 0, sizeof k->S.sun_orig);
+    k->w = p->width; k->h = p->height;
+    k->control = (G.est == VP_EST_DECOMP && G.trk == VP_TRACK_SPECTRAL) ? 1 : 0;
+    k->quant = G.quant; k->epoch = G.epoch;
+    const size_t need = (size_t)p->width * p->height * sizeof(float4);
+    if (key != G.crawl_key || !G.d_crawl)
+    {
+        if (la_quiesce()) return VP_E_NODEVICE;   // batches in flight read the old table
+        HIPCHK(hipStreamSynchronize(G.stream));
+        if (need > G.crawl_bytes)
+        {
+            if (G.d_crawl) HIPCHK(hipFree(G.d_crawl));
+            G.d_crawl = nullptr; G.crawl_bytes = 0; G.crawl_key.clear();
+            if (hipMalloc((void**)&G.d_crawl, need) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                G.d_crawl = nullptr;
+                return VP_OK;   // no table: the paths walk the crawl themselves, same bits
+            }
+            G.crawl_bytes = need;
+        }
+        launch_crawl_table(G.S, G.quant, p->width, p->height, k->control != 0, G.d_crawl, G.stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(G.stream));
+        G.crawl_key = key;
+    }
+    *out = G.d_crawl;
+    return VP_OK;
+}
+
 // where a render launch goes: the caller's stream with the shared staging buffer, or a look-ahead slot
 struct Target { hipStream_t stream; float4** stage; size_t* stage_bytes; unsigned* queue; };
 
@@ -445,8 +496,10 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     L.queue = T.queue;
     L.counters = G.count ? G.d_counters : nullptr;
     L.key0 = G.key0; L.key1 = G.key1;
-    L.wait_lanes = G.wait_lanes; L.wait_iters = G.wait_iters;
+    L.wait_lanes = G.wait_lanes; L.wait_iters = G.wait_iters; L.setup_lanes = G.setup_lanes;
     if (L.ntiles_owned == 0) return VP_OK;
+    rc = ensure_crawl_table(p, &L.crawl);
+    if (rc) return rc;
     const size_t per_frame = sh.per_frame;
     if (0xfffffff0u / per_frame < 1) return fail(VP_E_ARG, "image too large for the 32-bit sample queue");
     // the owned tile slots (row-major) split into VP_NQUEUES bands of whole tiles
@@ -785,6 +838,7 @@ int vp_ctx_destroy(vp_ctx* ctx)
         for (auto& ev : D.events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
         for (auto e : D.event_pool) (void)hipEventDestroy(e);
         if (D.d_stage) (void)hipFree(D.d_stage);
+        if (D.d_crawl) (void)hipFree(D.d_crawl);
         if (D.d_queue) (void)hipFree(D.d_queue);
         if (D.d_counters) (void)hipFree(D.d_counters);
         if (D.own_stream) (void)hipStreamDestroy(D.own_stream);
@@ -897,7 +951,7 @@ int vp_read_counters(vp_counters* out, int reset)
     int rc = ensure_device();
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(G.stream));
-    unsigned long long h[16];
+    unsigned long long h[kCounterWords];
     HIPCHK(hipMemcpy(h, G.d_counters, sizeof h, hipMemcpyDeviceToHost));
     if (out)
     {
@@ -906,6 +960,13 @@ int vp_read_counters(vp_counters* out, int reset)
         out->opacity_lookups = h[3]; out->env_lookups = h[4]; out->scatters = h[5];
         if (getenv("VP_DEBUG_COUNTERS")) fprintf(stderr, "[vp] wave-iterations %llu, active lane-steps %llu (%.1f per iteration), slow-path visits %llu (every %.1f iterations), shadow lane-steps %llu; wave cycles: slow path %llu, fast loop %llu (%.1f%% slow, %.0f cycles per visit, %.0f per step)\n", h[6], h[7], h[6] ? (double)h[7] / h[6] : 0.0, h[8], h[8] ? (double)h[6] / h[8] : 0.0, h[9], h[10], h[11], 100.0 * h[10] / (double)(h[10] + h[11] + 1), h[8] ? (double)h[10] / h[8] : 0.0, h[6] ? (double)h[11] / h[6] : 0.0);
     }
+        if (getenv("VP_DEBUG_COUNTERS"))
+        {
+            static const char* names[11] = {"setup", "half-step", "lookup+collision", "segment/ray end", "scatter", "nee", "phase", "background", "write", "refill", "global set-up"};
+            fprintf(stderr, "[vp] block: wave executions, lanes per execution (of 64)\n");
+            for (int b = 0; b < 11; b++)
+                if (h[16 + 2 * b]) fprintf(stderr, "[vp]   %-18s %14llu  %5.1f\n", names[b], h[16 + 2 * b], (double)h[17 + 2 * b] / (double)h[16 + 2 * b]);
+        }
     if (reset) HIPCHK(hipMemset(G.d_counters, 0, sizeof h));
     return VP_OK;
 }

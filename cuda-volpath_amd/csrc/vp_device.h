@@ -102,6 +102,8 @@ struct RngSamplerH
     // the reference's stream is sequential: the pair tags of the counter-based generator mean nothing here
     __device__ __forceinline__ float next_a() { return next(); }
     __device__ __forceinline__ float next_b() { return next(); }
+    // discard n draws (values that cannot influence the path: the restart crawl in front of the volume)
+    __device__ __forceinline__ void skip(unsigned n) { for (unsigned i = 0; i < n; i++) word(); }
 };
 
 // Philox2x32-10 (Salmon et al., SC'11), numbered in PAIRS of draws: next_a() computes
@@ -120,8 +122,11 @@ struct RngPhilox
     __device__ __forceinline__ float next_a()
     {
         unsigned c0 = pair, c1 = pix, k = key;
+#ifndef VP_PHILOX_ROUNDS
+#define VP_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-        for (int r = 0; r < 10; r++)
+        for (int r = 0; r < VP_PHILOX_ROUNDS; r++)
         {
             unsigned long long p = (unsigned long long)0xD256D193u * c0;
             unsigned n0 = (unsigned)(p >> 32) ^ k ^ c1;
@@ -134,6 +139,8 @@ struct RngPhilox
         return u2f(0x3f800000u | (c0 >> 9)) - 1.0f;
     }
     __device__ __forceinline__ float next_b() { return u2f(0x3f800000u | (w1 >> 9)) - 1.0f; }
+    // discard n pairs: the counter moves, nothing is computed
+    __device__ __forceinline__ void skip(unsigned n) { pair += n; }
 };
 
 // ------------------------------------------------------------------ texture fetches
@@ -369,6 +376,16 @@ __device__ __forceinline__ bool intersect_box_inv(f3 o, f3 invR, const SceneDev&
     tnear = largest_tmin;
     tfar  = smallest_tmax;
     return smallest_tmax > largest_tmin && smallest_tmax >= 1e-3f;
+}
+
+// camera ray of a pixel, kernel.cu:1977-1987 (quirk Q3: no jitter -- the same ray in every frame)
+__device__ __forceinline__ void camera_ray(const SceneDev& S, unsigned width, unsigned height, unsigned px, unsigned py, f3& ro, f3& rd)
+{
+    float u = ((float)px * 2.0f - (float)width) / (float)width;
+    float v = ((float)py * 2.0f - (float)height) / (float)width;
+    ro      = f3{S.cam[3], S.cam[7], S.cam[11]};
+    f3 dv   = f3{u, v, S.cam_z};
+    rd      = normalize(f3{dot(dv, f3{S.cam[0], S.cam[1], S.cam[2]}), dot(dv, f3{S.cam[4], S.cam[5], S.cam[6]}), dot(dv, f3{S.cam[8], S.cam[9], S.cam[10]})});
 }
 
 // Frame kernel.cu:557-573 (fabs(n.x) > 0.1 is a DOUBLE compare: equivalent to >= 0.1f in float)

@@ -27,6 +27,11 @@
 #ifndef VP_WAIT_ITERS
 #define VP_WAIT_ITERS 16
 #endif
+// lanes that must be waiting for a restart-segment set-up before it runs in the middle of a pass (it always runs at the first
+// step of a pass)
+#ifndef VP_SETUP_LANES
+#define VP_SETUP_LANES 8
+#endif
 // tracking steps per pass of the inner loop: the wave-level bookkeeping (ballots, wait policy) is paid once per pass
 #ifndef VP_STEPS_PER_PASS
 #define VP_STEPS_PER_PASS 4
@@ -60,17 +65,20 @@ struct LaunchDev
     unsigned total_items;  // nframes * ntiles_owned * 64
     float4*  out;          // W*H accumulator (caller-owned)
     float4*  stage;        // [nframes][ntiles_owned*64] per-sample results, or null = accumulate directly
+    const float4* crawl;   // per pixel: where the restart crawl in front of the volume ends (crawl_table_k), or null
     unsigned* queue;       // VP_NQUEUES sample-queue heads, VP_QUEUE_STRIDE words apart (zeroed before the launch)
     unsigned q_start[VP_NQUEUES + 1];  // slot range [q_start[q], q_start[q+1]) of a frame that queue q hands out
     unsigned long long* counters;  // 6 words (samples, density, bound, opacity, env, scatters) or null
     unsigned key0, key1;   // Philox key
     unsigned wait_lanes, wait_iters;  // inner-loop exit policy (VP_WAIT_LANES / VP_WAIT_ITERS)
+    unsigned setup_lanes;  // lanes that must ask for a segment set-up before it runs mid-pass (VP_SETUP_LANES; 1 = at every step)
 };
 
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
                    int blocks, hipStream_t st);
 void launch_env_tables(const float4* env, int w, int h, float* lum, float* row_sum, float* cdf_x, float* cdf_y, float* pdfnorm_alt,
                        hipStream_t st);
+void launch_crawl_table(const SceneDev& S, bool quant, unsigned width, unsigned height, bool control_draw, float4* table, hipStream_t st);
 void launch_reduce(const LaunchDev& L, hipStream_t st);
 void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, hipStream_t st);
 void launch_pack_f32(const float* vol, float* cells, int nx, int ny, int nz, hipStream_t st);

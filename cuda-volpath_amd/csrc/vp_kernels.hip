@@ -13,6 +13,9 @@
 // (MIS = false, the shipped build) or 0 (MIS = true).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "vp_device.h"
 #include "vp_kernels.h"
 
@@ -107,6 +110,16 @@ void render_k(SceneDev S, LaunchDev L)
     unsigned long long c_den = 0, c_bnd = 0, c_opa = 0, c_env = 0, c_sca = 0, c_smp = 0;
     unsigned long long d_iter = 0, d_act = 0, d_outer = 0, d_shadow = 0;  // debug (lane 0 counts wave events)
     unsigned long long t_slow = 0, t_fast = 0, t_mark = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;  // shader cycles
+    // COUNT build: how often each code block runs (wave executions) and for how many lanes -- where the lane slots go
+    enum { B_SETUP, B_HALF, B_LOOK, B_EXIT, B_SCATTER, B_NEE, B_HG, B_BG, B_WRITE, B_REFILL, B_GSETUP, B_NBLK };
+    unsigned long long bw[B_NBLK] = {}, bl[B_NBLK] = {};
+    auto tally = [&](int b, bool on) __attribute__((always_inline)) {
+        if (COUNT)
+        {
+            unsigned long long m = __ballot(on);
+            if (m) { bw[b] += 1; bl[b] += (unsigned)__popcll(m); }
+        }
+    };
 
     const unsigned lane = threadIdx.x & 63u;
     unsigned chunk_next = 0, chunk_end = 0;  // wave-uniform
@@ -162,6 +175,7 @@ void render_k(SceneDev S, LaunchDev L)
             segment_medium();
         };
         // ---- collision: direct lighting set-up (kernel.cu:2161-2217 / :1458-1491)
+        tally(B_SCATTER, st == EV_SCATTER);
         if (st == EV_SCATTER)
         {
             if (COUNT) c_sca++;
@@ -221,6 +235,7 @@ void render_k(SceneDev S, LaunchDev L)
         for (int pass = 0; pass < (MIS ? 2 : 1); pass++)
         {
             // ---- a light estimate is complete (kernel.cu:2188-2189,:2209-2210 and :2254,:2290)
+            tally(B_NEE, st == EV_NEE);
             if (st == EV_NEE)
             {
                 if (MIS)
@@ -284,6 +299,7 @@ void render_k(SceneDev S, LaunchDev L)
             }
         }
         // ---- phase-function sampling (kernel.cu:2301-2303)
+        tally(B_HG, st == EV_HG);
         if (st == EV_HG)
         {
             Frame fr(pd);
@@ -298,6 +314,7 @@ void render_k(SceneDev S, LaunchDev L)
         {
             // order: a path that ends here is written, its lane refilled and the new segment set up in ONE round
             // ---- ray left the medium: background() kernel.cu:1258-1267 (quirk Q11)
+            tally(B_BG, st == EV_BG);
             if (st == EV_BG)
             {
                 // with active environment sampling only unscattered paths see it directly (kernel.cu:2026-2030, :1340-1344)
@@ -311,6 +328,7 @@ void render_k(SceneDev S, LaunchDev L)
                 st = EV_WRITE;
             }
             // ---- path end: emit the sample (kernel.cu:2306-2316 / :1579-1589)
+            tally(B_WRITE, st == EV_WRITE);
             if (st == EV_WRITE)
             {
                 f3     r    = rad * P.brightness;
@@ -334,6 +352,7 @@ void render_k(SceneDev S, LaunchDev L)
             {
                 bool               need = (st == ST_DONE) && !exhausted;
                 unsigned long long m    = __ballot(need);
+                tally(B_REFILL, need);
                 if (m)
                 {
                     while (chunk_next >= chunk_end && !queue_empty)
@@ -390,17 +409,23 @@ void render_k(SceneDev S, LaunchDev L)
                                     chan     = (int)fminf((1.0f - rng.next_a()) * 3.0f, 2.9999998f);  // kernel.cu:1993
                                     sig_base = density * (chan == 0 ? P.sigma_t[0] : chan == 1 ? P.sigma_t[1] : P.sigma_t[2]);
                                 }
-                                float u = ((float)px * 2.0f - (float)P.width) / (float)P.width;
-                                float v = ((float)py * 2.0f - (float)P.height) / (float)P.width;
-                                ro      = f3{S.cam[3], S.cam[7], S.cam[11]};
-                                f3 dv   = f3{u, v, S.cam_z};
-                                rd = normalize(f3{dot(dv, f3{S.cam[0], S.cam[1], S.cam[2]}), dot(dv, f3{S.cam[4], S.cam[5], S.cam[6]}),
-                                                  dot(dv, f3{S.cam[8], S.cam[9], S.cam[10]})});
+                                camera_ray(S, P.width, P.height, px, py, ro, rd);
                                 if (LOCAL) inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
                                 thr = f3{1.0f, 1.0f, 1.0f};
                                 rad = f3{0.0f, 0.0f, 0.0f};
                                 nsc = 0;
                                 seg = 0;
+                                if (LOCAL && L.crawl)
+                                {
+                                    // the restart crawl in front of the volume, done once per pixel by crawl_table_k: the path starts
+                                    // where that crawl ends, with its draws skipped and its segments counted
+                                    float4   c = L.crawl[(size_t)px + (size_t)py * P.width];
+                                    unsigned k = f2u(c.w);
+                                    ro = f3{c.x, c.y, c.z};
+                                    rng.skip(k >> 16);
+                                    if (EST == EST_BOUNDED) seg = (int)(k & 0xffffu);
+                                    if (COUNT) c_bnd += k & 0xffffu;
+                                }
                                 st  = ST_SETUP;
                                 segment_medium();
                                 if (COUNT) c_smp++;
@@ -412,6 +437,7 @@ void render_k(SceneDev S, LaunchDev L)
                 }
             }
             // ---- global-majorant segment set-up (__d_render kernel.cu:1332-1370); rare, so it lives here
+            if (EST == EST_GLOBAL) tally(B_GSETUP, st == ST_SETUP);
             if (EST == EST_GLOBAL && st == ST_SETUP)
             {
                 float t_near, tf;
@@ -450,6 +476,7 @@ void render_k(SceneDev S, LaunchDev L)
         // one segment set-up (local-majorant estimators) and one tracking step, as lambdas: the loop below runs
         // them twice per pass so that the wave-level bookkeeping (ballots, wait policy) is paid once per two steps
         auto segment_setup = [&]() __attribute__((always_inline)) {
+            if (LOCAL) tally(B_SETUP, st == ST_SETUP);
             if (LOCAL && st == ST_SETUP)
             {
                 // intersectSuperVolume kernel.cu:1626-1661 (quirks Q6, Q10): the bound is fetched before the hit test
@@ -500,10 +527,13 @@ void render_k(SceneDev S, LaunchDev L)
             }
         };
         auto tracking_step = [&]() __attribute__((always_inline)) {
+            tally(B_HALF, st == ST_TRACK || st == ST_SHADOW);
             if (st == ST_TRACK || st == ST_SHADOW)
             {
                 const bool shadow = st == ST_SHADOW;
                 dist += -logf_(rng.next_a()) * inv_sigma;  // kernel.cu:2085 / :784
+                tally(B_EXIT, dist >= t_end || (shadow && terms == 7));
+                tally(B_LOOK, !(dist >= t_end || (shadow && terms == 7)));
                 if (dist >= t_end || (shadow && terms == 7))
                 {
                     if (shadow)
@@ -570,7 +600,7 @@ void render_k(SceneDev S, LaunchDev L)
                         float Pn   = (mn + mn) + mn;
                         float c    = Ps + Pn;
                         bool  real = e * c < Ps;
-                        float f    = inv_sigma_t * c / (real ? Ps : Pn);
+                        float f    = wdiv_(inv_sigma_t * c, real ? Ps : Pn);
                         thr.x      = thr.x * ((real ? a_s : a_n) * f);
                         if (real)
                         {
@@ -597,7 +627,7 @@ void render_k(SceneDev S, LaunchDev L)
                                    __builtin_fabsf(sigma_null_den.z * thr.z);
                         float c    = Ps + Pn;
                         bool  real = e * c < Ps;
-                        float f    = inv_sigma_t * c / (real ? Ps : Pn);
+                        float f    = wdiv_(inv_sigma_t * c, real ? Ps : Pn);
                         f3    sel  = real ? sigma_s_den : sigma_null_den;
                         thr        = thr * (sel * f);
                         if (real)
@@ -630,7 +660,10 @@ void render_k(SceneDev S, LaunchDev L)
                     unsigned long long am2 = __ballot((st == ST_TRACK) || (st == ST_SHADOW) || (LOCAL && st == ST_SETUP));
                     if (lane == 0) { d_iter++; d_act += (unsigned)__popcll(am2); d_shadow += (unsigned)__popcll(__ballot(st == ST_SHADOW)); }
                 }
-                segment_setup();
+                // a restart segment is set up at once while many lanes ask for one (the crawl toward and through empty bricks,
+                // quirk Q6); a few stragglers -- a dense region ends a 0.05 segment every ~40 steps per lane -- wait for the
+                // first step of the next pass, so that the ~100 instructions of the set-up are not run for one or two lanes
+                if (LOCAL && (unsigned)__popcll(__ballot(st == ST_SETUP)) >= L.setup_lanes) segment_setup();
                 tracking_step();
             }
         }
@@ -648,7 +681,48 @@ void render_k(SceneDev S, LaunchDev L)
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0) atomicAdd(&L.counters[q], v);
         }
+        // block tallies are wave-uniform: lane 0 adds them
+        if (lane == 0)
+        {
+#pragma unroll
+            for (int b = 0; b < B_NBLK; b++) { atomicAdd(&L.counters[16 + 2 * b], bw[b]); atomicAdd(&L.counters[17 + 2 * b], bl[b]); }
+        }
     }
+}
+
+// The restart crawl in front of the volume (quirk Q6), once per pixel.  The reference measures a segment's end
+// t_far = min(t_exit, 0.05) from the ray origin even while the origin is outside the box (kernel.cu:1653-1654), so a camera
+// 2.9 units away walks ~58 segments of 0.05 toward the volume, each one a bound fetch at the box entry point, one or two
+// draws and `origin += d * 0.05` (kernel.cu:2151-2155).  While t_near >= t_far such a segment cannot collide: the free flight
+// starts at dist = t_near and only grows (dist += -log(u) / sigma >= t_near >= t_far, likewise the control distance), so
+// `through` (kernel.cu:2145) holds whatever the draws are.  The camera ray is the same in every frame (quirk Q3), hence so is
+// this walk: the table holds, per pixel, the origin the walk ends at (the identical binary32 additions), the number of
+// segments walked (16 bits: the bounded kernel counts them, kernel.cu:1716) and the number of draws they consume (one per
+// segment, one more where the entry brick has a positive minimum and the decomposition estimator draws its control distance,
+// kernel.cu:2048-2054).  A path then starts at the first segment that can interact.  Bit-identical by construction.
+template <bool QUANT>
+__global__ __launch_bounds__(256) void crawl_table_k(SceneDev S, unsigned width, unsigned height, int control_draw, float4* table)
+{
+    unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= width * height) return;
+    unsigned py = idx / width, px = idx - py * width;
+    f3 ro, rd;
+    camera_ray(S, width, height, px, py, ro, rd);
+    f3 inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
+    unsigned segs = 0, draws = 0;
+    for (; segs < 700u; segs++)   // far below the bounded kernel's 800-segment cap, and both counts stay within 16 bits
+    {
+        float t_near, tf;
+        bool  hit = intersect_box_inv(ro, inv_rd, S, t_near, tf);
+        t_near    = fmaxf(t_near, 0.0f);
+        float t_far = fminf(tf, 0.05f);
+        if (!hit || !(t_near >= t_far)) break;   // a NaN anywhere ends the walk: the path itself takes over
+        float bx, by;
+        sample_bound<QUANT>(S, ro + rd * t_near, bx, by);
+        draws += (control_draw && by > 0.0f) ? 2u : 1u;
+        ro = ro + rd * t_far;
+    }
+    table[idx] = make_float4(ro.x, ro.y, ro.z, u2f(segs | (draws << 16)));
 }
 
 // per pixel, add the staged samples in frame order:  acc = (((acc + s0) + s1) + ...)
@@ -914,6 +988,16 @@ template <int EST, class RNG, bool LDSB, bool ACH, bool MIS>
 static void launch_render5(const SceneDev& S, const LaunchDev& L, bool quant, bool count, int blocks, hipStream_t st)
 {
     const dim3 blk(LDSB ? VP_BLOCK_LDS : VP_BLOCK);
+#ifdef VP_DEV_BUILD
+    quant = true;
+    if (MIS) return;
+    if constexpr (!MIS)
+    {
+        if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB, ACH, false, 0>), dim3(blocks), blk, 0, st, S, L);
+        else hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB, ACH, false, 0>), dim3(blocks), blk, 0, st, S, L);
+    }
+    return;
+#endif
     if (quant)
     {
         if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB, ACH, MIS, 0>), dim3(blocks), blk, 0, st, S, L);
@@ -958,6 +1042,26 @@ static void launch_render3(const SceneDev& S, const LaunchDev& L, bool quant, bo
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
                    int blocks, hipStream_t st)
 {
+#ifdef VP_DEV_BUILD
+    // development build (make DEV=1 -> libvolpath_hip_dev.so): only the kernels of the bench workloads are compiled
+    // (Philox streams, uchar volume, spectral tracking, passive environment; global-majorant and decomposition estimators)
+    {
+        const ParamDev& Pd = L.P;
+        const bool achd = Pd.sigma_t[0] == Pd.sigma_t[1] && Pd.sigma_t[1] == Pd.sigma_t[2] && Pd.albedo[0] == Pd.albedo[1] && Pd.albedo[1] == Pd.albedo[2];
+        if (trk || mis || !quant || rng != RNG_PHILOX || est == EST_BOUNDED)
+        {
+            fprintf(stderr, "volpath_hip DEV build: this kernel variant is not compiled\n");
+            abort();
+        }
+        if (est == EST_DECOMP)
+        {
+            if (lds_bounds) launch_render3<EST_DECOMP, RngPhilox, true>(S, L, true, count, achd, false, blocks, st);
+            else launch_render3<EST_DECOMP, RngPhilox, false>(S, L, true, count, achd, false, blocks, st);
+        }
+        else launch_render3<EST_GLOBAL, RngPhilox, false>(S, L, true, count, achd, false, blocks, st);
+        return;
+    }
+#else
     if (trk)
     {
         const bool ph = rng == RNG_PHILOX;
@@ -994,6 +1098,7 @@ void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool
         if (rng == RNG_PHILOX) launch_render3<EST_GLOBAL, RngPhilox, false>(S, L, quant, count, ach, mis, blocks, st);
         else launch_render3<EST_GLOBAL, RngSamplerH, false>(S, L, quant, count, ach, mis, blocks, st);
     }
+#endif
 }
 
 // ------------------------------------------------------------------ environment CDF tables (init_envmap, kernel.cu:1144-1210)
@@ -1045,6 +1150,12 @@ void launch_env_tables(const float4* env, int w, int h, float* lum, float* row_s
     hipLaunchKernelGGL(env_lum_k, dim3((n + 255) / 256), dim3(256), 0, st, env, lum, w, h);
     hipLaunchKernelGGL(env_row_cdf_k, dim3((h + 63) / 64), dim3(64), 0, st, lum, cdf_x, row_sum, w, h);
     hipLaunchKernelGGL(env_col_cdf_k, dim3(1), dim3(64), 0, st, lum, row_sum, cdf_y, pdfnorm_alt, w, h);
+}
+void launch_crawl_table(const SceneDev& S, bool quant, unsigned width, unsigned height, bool control_draw, float4* table, hipStream_t st)
+{
+    unsigned n = width * height;
+    if (quant) hipLaunchKernelGGL(crawl_table_k<true>, dim3((n + 255) / 256), dim3(256), 0, st, S, width, height, control_draw ? 1 : 0, table);
+    else hipLaunchKernelGGL(crawl_table_k<false>, dim3((n + 255) / 256), dim3(256), 0, st, S, width, height, control_draw ? 1 : 0, table);
 }
 void launch_reduce(const LaunchDev& L, hipStream_t st)
 {

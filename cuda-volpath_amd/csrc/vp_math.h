@@ -17,6 +17,9 @@ __device__ __forceinline__ unsigned f2u(float f) { return __float_as_uint(f); }
 // natural logarithm on {0} U [2^-126, inf); log(0) = -inf
 __device__ __forceinline__ float logf_(float x)
 {
+#ifdef VP_EXP_FASTLOG
+    return __builtin_amdgcn_logf(x) * 0.69314718056f;
+#endif
     // mantissa folded into (sqrt(2)/2, sqrt(2)] without a select: adding 2^23 - 0x3504f4 to the bit pattern carries
     // into the exponent field exactly when the mantissa field exceeds that of fl(sqrt 2) = 0x3fb504f3
     unsigned ix = f2u(x);
@@ -123,6 +126,16 @@ __device__ __forceinline__ float atanf_(float x)
     p       = fma_(p, z, -3.33329491539E-1f);
     y       = y + fma_(p * z, t, t);
     return x < 0.0f ? -y : y;
+}
+
+// the quotient of the collision weights (experiment hook: VP_EXP_FASTDIV replaces the IEEE divide by v_rcp_f32)
+__device__ __forceinline__ float wdiv_(float a, float b)
+{
+#ifdef VP_EXP_FASTDIV
+    return a * __builtin_amdgcn_rcpf(b);
+#else
+    return a / b;
+#endif
 }
 
 __device__ __forceinline__ float pow15f_(float x) { return x * __builtin_sqrtf(x); }

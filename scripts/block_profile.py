@@ -1,0 +1,16 @@
+"""Where the lane slots go: block tallies of the counting kernel variant (VP_DEBUG_COUNTERS=1).
+   python scripts/block_profile.py c3 [FRAMES]"""
+import os, sys
+os.environ["VP_DEBUG_COUNTERS"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cuda-volpath_amd"))
+import volpath as vp
+from volpath import scene
+wl = sys.argv[1]; frames = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+vp.set_device(0)
+P, info = scene.setup(wl, rng_mode=vp.RNG_PHILOX, last_frame=frames)
+buf = vp.DeviceBuffer(P.width, P.height)
+vp.enable_counters(True); vp.read_counters()
+vp.render_frames(buf.ptr, 0, frames, P)
+c = vp.read_counters()
+print(wl, {k: round(v / c["samples"], 2) for k, v in c.items()})
