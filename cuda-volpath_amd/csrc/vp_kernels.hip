@@ -123,6 +123,7 @@ void render_k(SceneDev S, LaunchDev L)
 
     const unsigned lane = threadIdx.x & 63u;
     unsigned chunk_next = 0, chunk_end = 0;  // wave-uniform
+    unsigned chunk_base = 0, chunk_fl = 0, chunk_ot0 = 0, chunk_ty0 = 0, chunk_j0 = 0;  // of the current chunk (wave-uniform)
     bool     queue_empty = false;
     // the queue this wave draws from: its XCD's first (HW_REG_XCC_ID, bits 3:0), then the others in turn
     unsigned q_cur   = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & (VP_NQUEUES - 1);
@@ -219,6 +220,11 @@ void render_k(SceneDev S, LaunchDev L)
                 if (TRK)
                 {
                     float a = expf_(-stp2 * op);  // kernel.cu:2190
+                    nee_a   = f3{a, a, a};
+                }
+                else if (ACH)
+                {
+                    float a = expf_(((-sig_t.x) * dp2) * op);  // the three channels are the same expression
                     nee_a   = f3{a, a, a};
                 }
                 else
@@ -371,8 +377,15 @@ void render_k(SceneDev S, LaunchDev L)
                         if (c < cpf * (unsigned)L.nframes)
                         {
                             const unsigned pos = c / (unsigned)L.nframes, fl = c - pos * (unsigned)L.nframes, off = pos * (unsigned)VP_CHUNK;
-                            chunk_next = fl * (L.ntiles_owned * 64u) + q0 + off;
+                            chunk_base = fl * (L.ntiles_owned * 64u);
+                            chunk_next = chunk_base + q0 + off;
                             chunk_end  = chunk_next + (len - off < (unsigned)VP_CHUNK ? len - off : (unsigned)VP_CHUNK);
+                            // the chunk lies in ONE frame and covers a few consecutive tile slots: its frame and the tile row /
+                            // column of its first slot are found once here, so that a refill needs no integer division per lane
+                            chunk_fl   = fl;
+                            chunk_ot0  = (q0 + off) >> 6;
+                            chunk_ty0  = chunk_ot0 / L.tiles_per_row;
+                            chunk_j0   = chunk_ot0 - chunk_ty0 * L.tiles_per_row;
                         }
                         else
                         {
@@ -391,15 +404,18 @@ void render_k(SceneDev S, LaunchDev L)
                         else
                         {
                             item = chunk_next + rank;
-                            unsigned per_frame = L.ntiles_owned * 64u;
-                            unsigned fl  = item / per_frame;
-                            unsigned rem = item - fl * per_frame;
+                            unsigned rem = item - chunk_base;          // slot within the frame
                             unsigned ot  = rem >> 6, w = rem & 63u;
-                            unsigned tx, ty;
-                            owned_tile(ot, L.tiles_per_row, L.rank, L.world, tx, ty);
+                            // owned_tile(ot, ...) from the chunk's first slot: at most VP_CHUNK / 64 slots further on
+                            unsigned j = chunk_j0 + (ot - chunk_ot0), ty = chunk_ty0;
+#pragma unroll
+                            for (int k = 0; k < VP_CHUNK / 64; k++)
+                                if (j >= L.tiles_per_row) { j -= L.tiles_per_row; ty++; }
+                            unsigned tx = j;
+                            if (L.world > 1) tx = j * L.world + (L.rank + L.world - tile_row_shift(ty, L.world)) % L.world;
                             px    = tx * 8u + (w & 7u);
                             py    = ty * 8u + (w >> 3);
-                            frame = L.frame0 + (int)fl;
+                            frame = L.frame0 + (int)chunk_fl;
                             if (px < P.width && py < P.height)
                             {
                                 // camera ray, kernel.cu:1977-1987 (quirk Q3)
@@ -996,8 +1012,7 @@ static void launch_render5(const SceneDev& S, const LaunchDev& L, bool quant, bo
         if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB, ACH, false, 0>), dim3(blocks), blk, 0, st, S, L);
         else hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB, ACH, false, 0>), dim3(blocks), blk, 0, st, S, L);
     }
-    return;
-#endif
+#else
     if (quant)
     {
         if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB, ACH, MIS, 0>), dim3(blocks), blk, 0, st, S, L);
@@ -1008,6 +1023,7 @@ static void launch_render5(const SceneDev& S, const LaunchDev& L, bool quant, bo
         if (count) hipLaunchKernelGGL((render_k<EST, RNG, false, true, false, ACH, MIS, 0>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
         else hipLaunchKernelGGL((render_k<EST, RNG, false, false, false, ACH, MIS, 0>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
     }
+#endif
 }
 // scalar tracking builds (the reference's compiled-out SPECTRAL_TRACKING 0 / MULTI_CHANNEL 1): three-channel throughput, no
 // LDS / MIS / counting specialisations
