@@ -483,6 +483,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         return fail(VP_E_ARG, "image %ux%u out of range (sampler.h packs x<<16|y)", p->width, p->height);
     if (G.trk && G.env_mis) return fail(VP_E_STATE, "scalar tracking builds exist with passive environment lighting only");
     if (G.trk && G.count) return fail(VP_E_STATE, "work counters are not built for the scalar tracking kernels");
+    if (G.rng == VP_RNG_PHILOX7 && (G.trk || G.env_mis))
+        return fail(VP_E_STATE, "VP_RNG_PHILOX7 is built for spectral tracking with passive environment lighting only");
     if (G.est == VP_EST_DECOMP && first + nframes - 1 > 10 && !G.S.opacity)
         return fail(VP_E_NOOPACITY, "frames beyond 10 need precompute_opacity (kernel.cu:2183, host.cpp:336-343)");
     LaunchDev L = {};
@@ -891,7 +893,7 @@ int vp_set_estimator(int est)
 }
 int vp_set_rng(int mode, uint32_t k0, uint32_t k1)
 {
-    if (mode != VP_RNG_SAMPLERH && mode != VP_RNG_PHILOX) return fail(VP_E_ARG, "unknown rng %d", mode);
+    if (mode != VP_RNG_SAMPLERH && mode != VP_RNG_PHILOX && mode != VP_RNG_PHILOX7) return fail(VP_E_ARG, "unknown rng %d", mode);
     G.rng = mode; G.key0 = k0; G.key1 = k1;
     return VP_OK;
 }

@@ -106,12 +106,13 @@ struct RngSamplerH
     __device__ __forceinline__ void skip(unsigned n) { for (unsigned i = 0; i < n; i++) word(); }
 };
 
-// Philox2x32-10 (Salmon et al., SC'11), numbered in PAIRS of draws: next_a() computes
+// Philox2x32-R (Salmon et al., SC'11; R = 10 or 7), numbered in PAIRS of draws: next_a() computes
 // philox2x32_10(counter = (pair index, x<<16|y), key = (frame ^ k0) + k1) and returns word 0, next_b() returns
 // word 1 of the same block.  The integrator draws (free flight, collision test) and the two phase-function
 // variates as such pairs, so the ten multiply rounds sit at one place per tracking step, for the whole wave,
 // with no buffer bookkeeping; a pair whose second word is not needed just drops it.
-struct RngPhilox
+template <int ROUNDS>
+struct RngPhiloxR
 {
     unsigned pix, key, pair;  // next pair index to generate
     unsigned w1;              // second word of the current pair
@@ -122,11 +123,8 @@ struct RngPhilox
     __device__ __forceinline__ float next_a()
     {
         unsigned c0 = pair, c1 = pix, k = key;
-#ifndef VP_PHILOX_ROUNDS
-#define VP_PHILOX_ROUNDS 10
-#endif
 #pragma unroll
-        for (int r = 0; r < VP_PHILOX_ROUNDS; r++)
+        for (int r = 0; r < ROUNDS; r++)
         {
             unsigned long long p = (unsigned long long)0xD256D193u * c0;
             unsigned n0 = (unsigned)(p >> 32) ^ k ^ c1;
@@ -142,6 +140,8 @@ struct RngPhilox
     // discard n pairs: the counter moves, nothing is computed
     __device__ __forceinline__ void skip(unsigned n) { pair += n; }
 };
+typedef RngPhiloxR<10> RngPhilox;   // VP_RNG_PHILOX
+typedef RngPhiloxR<7>  RngPhilox7;  // VP_RNG_PHILOX7: Random123's smallest Crush-resistant round count
 
 // ------------------------------------------------------------------ texture fetches
 #define VP_U8_TRI_SCALE 2.3374372e-10f  // fl(1/(255*2^24)): full scale -> exactly 1.0f

@@ -52,7 +52,7 @@ __host__ __device__ inline void owned_tile(unsigned ot, unsigned tiles_per_row, 
 
 // same values as the VP_EST_* / VP_RNG_* enums of include/volpath.h
 constexpr int EST_GLOBAL = 0, EST_DECOMP = 1, EST_BOUNDED = 2;
-constexpr int RNG_SAMPLERH = 0, RNG_PHILOX = 1;
+constexpr int RNG_SAMPLERH = 0, RNG_PHILOX = 1, RNG_PHILOX7 = 2;
 
 // one render launch: frames [frame0, frame0+nframes) x the 8x8 pixel tiles this rank owns
 struct LaunchDev

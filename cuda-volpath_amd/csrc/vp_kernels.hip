@@ -1055,6 +1055,14 @@ static void launch_render3(const SceneDev& S, const LaunchDev& L, bool quant, bo
     else launch_render5<EST, RNG, LDSB, false, false>(S, L, quant, count, blocks, st);
 }
 
+// VP_RNG_PHILOX7: the shipped configuration only (spectral tracking, passive environment)
+template <int EST, bool LDSB>
+static void launch_render_p7(const SceneDev& S, const LaunchDev& L, bool quant, bool count, bool ach, int blocks, hipStream_t st)
+{
+    if (ach) launch_render5<EST, RngPhilox7, LDSB, true, false>(S, L, quant, count, blocks, st);
+    else launch_render5<EST, RngPhilox7, LDSB, false, false>(S, L, quant, count, blocks, st);
+}
+
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
                    int blocks, hipStream_t st)
 {
@@ -1064,10 +1072,17 @@ void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool
     {
         const ParamDev& Pd = L.P;
         const bool achd = Pd.sigma_t[0] == Pd.sigma_t[1] && Pd.sigma_t[1] == Pd.sigma_t[2] && Pd.albedo[0] == Pd.albedo[1] && Pd.albedo[1] == Pd.albedo[2];
-        if (trk || mis || !quant || rng != RNG_PHILOX || est == EST_BOUNDED)
+        if (trk || mis || !quant || (rng != RNG_PHILOX && rng != RNG_PHILOX7) || est == EST_BOUNDED)
         {
             fprintf(stderr, "volpath_hip DEV build: this kernel variant is not compiled\n");
             abort();
+        }
+        if (rng == RNG_PHILOX7)
+        {
+            if (est == EST_DECOMP && lds_bounds) launch_render_p7<EST_DECOMP, true>(S, L, true, count, achd, blocks, st);
+            else if (est == EST_DECOMP) launch_render_p7<EST_DECOMP, false>(S, L, true, count, achd, blocks, st);
+            else launch_render_p7<EST_GLOBAL, false>(S, L, true, count, achd, blocks, st);
+            return;
         }
         if (est == EST_DECOMP)
         {
@@ -1090,6 +1105,15 @@ void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool
     const ParamDev& P = L.P;
     const bool ach = P.sigma_t[0] == P.sigma_t[1] && P.sigma_t[1] == P.sigma_t[2] && P.albedo[0] == P.albedo[1] &&
                      P.albedo[1] == P.albedo[2];
+    if (rng == RNG_PHILOX7)
+    {
+        // (mis and trk were rejected by the API for this generator)
+        if (est == EST_DECOMP && lds_bounds && quant) launch_render_p7<EST_DECOMP, true>(S, L, quant, count, ach, blocks, st);
+        else if (est == EST_DECOMP) launch_render_p7<EST_DECOMP, false>(S, L, quant, count, ach, blocks, st);
+        else if (est == EST_BOUNDED) launch_render_p7<EST_BOUNDED, false>(S, L, quant, count, ach, blocks, st);
+        else launch_render_p7<EST_GLOBAL, false>(S, L, quant, count, ach, blocks, st);
+        return;
+    }
     if (est == EST_DECOMP)
     {
         if (lds_bounds && quant && !mis)
@@ -1256,6 +1280,7 @@ void launch_test_math(int which, const float* in, float* out, int n, hipStream_t
 void launch_test_rng(int mode, unsigned x, unsigned y, unsigned f, unsigned k0, unsigned k1, int n, float* out, hipStream_t st)
 {
     if (mode == RNG_PHILOX) hipLaunchKernelGGL(test_rng_k<RngPhilox>, dim3(1), dim3(64), 0, st, x, y, f, k0, k1, n, out);
+    else if (mode == RNG_PHILOX7) hipLaunchKernelGGL(test_rng_k<RngPhilox7>, dim3(1), dim3(64), 0, st, x, y, f, k0, k1, n, out);
     else hipLaunchKernelGGL(test_rng_k<RngSamplerH>, dim3(1), dim3(64), 0, st, x, y, f, k0, k1, n, out);
 }
 void launch_test_density(const SceneDev& S, bool quant, const float* pos, float* out, int n, hipStream_t st)

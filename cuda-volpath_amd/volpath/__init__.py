@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VOLPATH_LIB", os.path.join(os.path.dirname(_HERE), "libvolpath_hip.so"))  # override: A/B builds
 
 EST_GLOBAL, EST_DECOMP, EST_BOUNDED = 0, 1, 2
-RNG_SAMPLERH, RNG_PHILOX = 0, 1
+RNG_SAMPLERH, RNG_PHILOX, RNG_PHILOX7 = 0, 1, 2
 ENV_PASSIVE, ENV_MIS = 0, 1
 TRACK_SPECTRAL, TRACK_SCALAR, TRACK_MULTI_CHANNEL = 0, 1, 2
 

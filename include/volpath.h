@@ -107,7 +107,9 @@ enum { VP_EST_GLOBAL = 0, /* __d_render, kernel.cu:1285-1591: global majorant (B
        VP_EST_BOUNDED = 2 /* __d_render_bounded, kernel.cu:1667-1952: local majorant, no control component,
                              800 tracked segments at most, heat = segments * 0.001, never reads the opacity volume */ };
 enum { VP_RNG_SAMPLERH = 0, /* src/sampler.h bit-compatible streams (parity mode) */
-       VP_RNG_PHILOX   = 1  /* Philox2x32-10, counter = (draw/2, x<<16|y), key = (frame ^ key0) + key1 */ };
+       VP_RNG_PHILOX   = 1, /* Philox2x32-10, counter = (draw/2, x<<16|y), key = (frame ^ key0) + key1 */
+       VP_RNG_PHILOX7  = 2  /* Philox2x32-7 (the fewest rounds Random123 documents as Crush-resistant), same counter / key;
+                               built for the shipped configuration (spectral tracking, passive environment) */ };
 
 const char* vp_last_error(void);
 const char* vp_version(void);

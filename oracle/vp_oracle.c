@@ -65,10 +65,10 @@ uint32_t vpo_hash(uint32_t seed)
 
 /* Random123 philox2x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): the
  * counter-based generator north_star asks for in place of sampler.h.  One call = two 32-bit words. */
-void vpo_philox2x32_10(const uint32_t ctr[2], uint32_t key, uint32_t out[2])
+void vpo_philox2x32_r(int rounds, const uint32_t ctr[2], uint32_t key, uint32_t out[2])
 {
     uint32_t c0 = ctr[0], c1 = ctr[1], k = key;
-    for (int r = 0; r < 10; r++)
+    for (int r = 0; r < rounds; r++)
     {
         uint64_t p  = (uint64_t)0xD256D193u * c0;
         uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
@@ -78,6 +78,10 @@ void vpo_philox2x32_10(const uint32_t ctr[2], uint32_t key, uint32_t out[2])
     }
     out[0] = c0; out[1] = c1;
 }
+void vpo_philox2x32_10(const uint32_t ctr[2], uint32_t key, uint32_t out[2]) { vpo_philox2x32_r(10, ctr, key, out); }
+/* philox2x32-7: Random123 documents 7 as the smallest round count of this generator that passes BigCrush ("Crush-resistant");
+ * VPO_RNG_PHILOX7 uses it with the same counter / key layout */
+void vpo_philox2x32_7(const uint32_t ctr[2], uint32_t key, uint32_t out[2]) { vpo_philox2x32_r(7, ctr, key, out); }
 
 typedef struct
 {
@@ -136,7 +140,7 @@ static inline float rng_draw(rng_t* r, int second)
     else if (!second)
     {
         r->ctr[0] = r->n++;
-        vpo_philox2x32_10(r->ctr, r->key, r->buf);
+        vpo_philox2x32_r(r->mode == VPO_RNG_PHILOX7 ? 7 : 10, r->ctr, r->key, r->buf);
         w = r->buf[0];
     }
     else

@@ -33,7 +33,7 @@ typedef struct
     float    sigma_t[3];
 } vpo_param;
 
-enum { VPO_RNG_SAMPLERH = 0, VPO_RNG_PHILOX = 1 };
+enum { VPO_RNG_SAMPLERH = 0, VPO_RNG_PHILOX = 1 /* philox2x32-10 */, VPO_RNG_PHILOX7 = 2 /* philox2x32-7 */ };
 enum { VPO_EST_GLOBAL = 0 /* __d_render, kernel.cu:1285 */, VPO_EST_DECOMP = 1 /* __d_render_bounded_decomp, :1958 */,
        VPO_EST_BOUNDED = 2 /* __d_render_bounded, :1667 */ };
 
@@ -95,6 +95,7 @@ uint32_t vpo_hash(uint32_t seed);
 void     vpo_rng_stream(int mode, uint32_t x, uint32_t y, uint32_t frame, uint32_t k0, uint32_t k1, int n,
                         float* out);
 void     vpo_philox2x32_10(const uint32_t ctr[2], uint32_t key, uint32_t out[2]);
+void     vpo_philox2x32_7(const uint32_t ctr[2], uint32_t key, uint32_t out[2]);
 void     vpo_julia_voxelize(int n, uint8_t* grid);
 int      vpo_bound_radius(int nx, float search_radius);
 void     vpo_bounds_u8(const uint8_t* grid, int nx, int ny, int nz, int radius, int brick, uint8_t* out);

@@ -12,7 +12,7 @@ rep = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 vp.set_device(0)
 sky = scene.default_sunsky()
 for wl in wls:
-    P, info = scene.setup(wl, rng_mode=vp.RNG_PHILOX, last_frame=frames, sunsky=sky)
+    P, info = scene.setup(wl, rng_mode=int(os.environ.get("VP_PERF_RNG", vp.RNG_PHILOX)), last_frame=frames, sunsky=sky)
     buf = vp.DeviceBuffer(P.width, P.height)
     vp.render_frames(buf.ptr, 0, 2, P); vp.synchronize(); vp.render_time_ms()
     best = 0

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 _LIB = None
 
-RNG_SAMPLERH, RNG_PHILOX = 0, 1
+RNG_SAMPLERH, RNG_PHILOX, RNG_PHILOX7 = 0, 1, 2
 EST_GLOBAL, EST_DECOMP, EST_BOUNDED = 0, 1, 2
 
 
@@ -203,11 +203,11 @@ def rng_stream(mode, x, y, frame, n, key=(0, 0)):
     return out
 
 
-def philox(ctr, key):
-    """Philox2x32-10: ctr = (c0, c1), key = one word -> two words"""
+def philox(ctr, key, rounds=10):
+    """Philox2x32-10 / -7: ctr = (c0, c1), key = one word -> two words"""
     c = (C.c_uint32 * 2)(*ctr)
     o = (C.c_uint32 * 2)()
-    lib().vpo_philox2x32_10(c, C.c_uint32(key), o)
+    (lib().vpo_philox2x32_10 if rounds == 10 else lib().vpo_philox2x32_7)(c, C.c_uint32(key), o)
     return list(o)
 
 

@@ -31,8 +31,24 @@ def test_philox_random123_kat(oracle):
         assert s[n] == np.float32(np.uint32(0x3f800000 | (w >> 9)).view(np.float32) - np.float32(1.0))
 
 
+def test_philox7_random123_kat(oracle):
+    """VP_RNG_PHILOX7: philox2x32 with 7 rounds, Random123's published known answers (kat_vectors) and the stream layout"""
+    for kat in ANCH["philox2x32_7_random123_kat"]:
+        assert oracle.philox(kat["ctr"], kat["key"], rounds=7) == kat["out"]
+    s = oracle.rng_stream(oracle.RNG_PHILOX7, 3, 5, 7, 8, key=(11, 22))
+    for n in range(8):
+        w = oracle.philox([n // 2, (3 << 16) | 5], ((7 ^ 11) + 22) & 0xffffffff, rounds=7)[n % 2]
+        assert s[n] == np.float32(np.uint32(0x3f800000 | (w >> 9)).view(np.float32) - np.float32(1.0))
+    # statistical sanity of the streams the integrator sees: per-pixel streams are uncorrelated and uniform
+    a = np.stack([oracle.rng_stream(oracle.RNG_PHILOX7, x, 9, 4, 512, key=(1, 2)) for x in range(64)])
+    assert abs(a.mean() - 0.5) < 0.01 and abs(a.var() - 1 / 12) < 0.005
+    c = np.corrcoef(a)
+    assert np.abs(c - np.eye(64)).max() < 0.25
+    assert abs(np.corrcoef(a[:, :-1].ravel(), a[:, 1:].ravel())[0, 1]) < 0.02
+
+
 def test_rng_float_range(oracle):
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         s = oracle.rng_stream(mode, 17, 4, 99, 4096)
         assert s.min() >= 0.0 and s.max() < 1.0
 

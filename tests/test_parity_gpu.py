@@ -45,7 +45,7 @@ def _oracle_frames(osc, oP, frames):
 
 
 @pytest.mark.parametrize("est", [1, 0, 2])
-@pytest.mark.parametrize("rng_mode", [0, 1])
+@pytest.mark.parametrize("rng_mode", [0, 1, 2])
 def test_julia32_frames_bit_exact(vp, oracle, est, rng_mode):
     grid = oracle.julia(32)
     osc, oP, vP = _setup(vp, oracle, grid, est, rng_mode, brick=1, key=(123, 456))
@@ -110,7 +110,7 @@ def test_math_and_rng_bits(vp, oracle):
     for which, x in cases.items():
         assert np.array_equal(vp.test_math(which, x), oracle.math_array(which, x)), which
     assert vp.test_math(0, np.zeros(1, np.float32))[0] == -np.inf
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         a = vp.test_rng(mode, 3, 5, 7, 64, key=(11, 22))
         b = oracle.rng_stream(mode, 3, 5, 7, 64, key=(11, 22))
         assert np.array_equal(a, b)
