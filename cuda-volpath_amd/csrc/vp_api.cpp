@@ -86,6 +86,8 @@ struct State
     bool        use_lds_bounds = true;
     // where the restart crawl in front of the volume ends, per pixel (crawl_table_k); rebuilt when what it depends on changes
     bool        use_crawl_table = true;
+    bool        use_empty_table = true;   // global-majorant estimator: certified-empty distances of the camera rays
+    unsigned char* d_danger = nullptr;    // per cell: a non-empty cell within its 3x3x3 neighbourhood (danger_k)
     float4*     d_crawl     = nullptr;
     size_t      crawl_bytes = 0;
     std::vector<unsigned char> crawl_key;
@@ -188,6 +190,7 @@ int ensure_device()
     if (knob("VP_BLOCKS_PER_CU", 1, 8, v)) G.blocks_per_cu = (unsigned)v;
     if (knob("VP_NO_LDS_BOUNDS", 0, 1, v)) G.use_lds_bounds = v == 0;
     if (knob("VP_NO_CRAWL_TABLE", 0, 1, v)) G.use_crawl_table = v == 0;
+    if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;
     if (knob("VP_LOOKAHEAD", 0, 4096, v)) G.la_max = (int)v;
     G.dev_ready = true;
     return VP_OK;
@@ -203,6 +206,8 @@ int free_volume()
     if (G.d_cells) HIPCHK(hipFree(G.d_cells));
     if (G.d_bounds) HIPCHK(hipFree(G.d_bounds));
     if (G.d_opacity) HIPCHK(hipFree(G.d_opacity));
+    if (G.d_danger) HIPCHK(hipFree(G.d_danger));
+    G.d_danger = nullptr;
     G.d_cells = G.d_bounds = nullptr;
     G.d_opacity   = nullptr;
     G.S.cells_u8  = nullptr;
@@ -298,6 +303,13 @@ int do_init_volume_(const void* h_volume, vp_extent ext, bool quantized, const v
         S.bounds_f32 = (const float*)G.d_bounds;
         S.cells_f32  = (const float*)G.d_cells;
     }
+    // cells with a non-empty cell in their neighbourhood: input of the certified-empty table of the global-majorant estimator
+    if (G.use_empty_table && hipMalloc((void**)&G.d_danger, n) == hipSuccess)
+    {
+        launch_danger(S, quantized, G.d_danger, G.stream);
+        HIPCHK(hipGetLastError());
+    }
+    else { (void)hipGetLastError(); G.d_danger = nullptr; }  // no memory for it: the estimator fetches every cell, same bits
     HIPCHK(hipStreamSynchronize(G.stream));  // caller may free h_volume on return (host.cpp:1343); scratch freed by the guard
     S.linear      = G.linear ? 1 : 0;
     G.have_volume = true;
@@ -428,8 +440,10 @@ size_t stage_frames_cap(size_t per_frame, size_t have_bytes)
 int ensure_crawl_table(const Param* p, const float4** out)
 {
     *out = nullptr;
-    if (!G.use_crawl_table || G.est == VP_EST_GLOBAL) return VP_OK;
-    struct K { SceneDev S; unsigned w, h; int control, quant; unsigned long long epoch; };
+    const bool global = G.est == VP_EST_GLOBAL;
+    // the certificate of the global-majorant estimator is stated for trilinear fetches (cell = floor(p*N - 0.5))
+    if (global ? !(G.use_empty_table && G.d_danger && G.linear) : !G.use_crawl_table) return VP_OK;
+    struct K { SceneDev S; unsigned w, h; int control, quant, global; unsigned long long epoch; };
     std::vector<unsigned char> key(sizeof(K), 0);
     K* k = reinterpret_cast<K*>(key.data());
     memcpy(&k->S, &G.S, sizeof(SceneDev));
@@ -438,7 +452,7 @@ int ensure_crawl_table(const Param* p, const float4** out)
     memset(k->S.sun_dir, 0, sizeof k->S.sun_dir); memset(k->S.sun_power, 0, sizeof k->S.sun_power); memset(k->S.sun_orig, 0, sizeof k->S.sun_orig);
     k->w = p->width; k->h = p->height;
     k->control = (G.est == VP_EST_DECOMP && G.trk == VP_TRACK_SPECTRAL) ? 1 : 0;
-    k->quant = G.quant; k->epoch = G.epoch;
+    k->quant = G.quant; k->epoch = G.epoch; k->global = global ? 1 : 0;
     const size_t need = (size_t)p->width * p->height * sizeof(float4);
     if (key != G.crawl_key || !G.d_crawl)
     {
@@ -456,7 +470,13 @@ int ensure_crawl_table(const Param* p, const float4** out)
             }
             G.crawl_bytes = need;
         }
-        launch_crawl_table(G.S, G.quant, p->width, p->height, k->control != 0, G.d_crawl, G.stream);
+        if (global)
+        {
+            SceneDev S = G.S;
+            S.linear   = 1;
+            launch_empty_table(S, p->width, p->height, G.d_danger, G.d_crawl, G.stream);
+        }
+        else launch_crawl_table(G.S, G.quant, p->width, p->height, k->control != 0, G.d_crawl, G.stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(G.stream));
         G.crawl_key = key;
@@ -958,7 +978,7 @@ int vp_read_counters(vp_counters* out, int reset)
     if (out)
     {
         memset(out, 0, sizeof *out);
-        out->samples = h[0]; out->density_lookups = h[1]; out->density_loads = h[1]; out->bound_lookups = h[2];
+        out->samples = h[0]; out->density_lookups = h[1]; out->density_loads = h[12]; out->bound_lookups = h[2];
         out->opacity_lookups = h[3]; out->env_lookups = h[4]; out->scatters = h[5];
         if (getenv("VP_DEBUG_COUNTERS")) fprintf(stderr, "[vp] wave-iterations %llu, active lane-steps %llu (%.1f per iteration), slow-path visits %llu (every %.1f iterations), shadow lane-steps %llu; wave cycles: slow path %llu, fast loop %llu (%.1f%% slow, %.0f cycles per visit, %.0f per step)\n", h[6], h[7], h[6] ? (double)h[7] / h[6] : 0.0, h[8], h[8] ? (double)h[6] / h[8] : 0.0, h[9], h[10], h[11], 100.0 * h[10] / (double)(h[10] + h[11] + 1), h[8] ? (double)h[10] / h[8] : 0.0, h[6] ? (double)h[11] / h[6] : 0.0);
     }
