@@ -447,13 +447,13 @@ int ensure_crawl_table(const Param* p, const float4** out)
     std::vector<unsigned char> key(sizeof(K), 0);
     K* k = reinterpret_cast<K*>(key.data());
     memcpy(&k->S, &G.S, sizeof(SceneDev));
-    k->S.linear = 0; k->S.env = nullptr; k->S.opacity = nullptr; k->S.env_cdf_x = k->S.env_cdf_y = nullptr;  // not read by the walk
+    k->S.linear = G.linear ? 1 : 0; k->S.env = nullptr; k->S.opacity = nullptr; k->S.env_cdf_x = k->S.env_cdf_y = nullptr;  // not read by the walk
     k->S.env_w = k->S.env_h = 0; k->S.env_pdfnorm_alt = 0.0f;
     memset(k->S.sun_dir, 0, sizeof k->S.sun_dir); memset(k->S.sun_power, 0, sizeof k->S.sun_power); memset(k->S.sun_orig, 0, sizeof k->S.sun_orig);
     k->w = p->width; k->h = p->height;
     k->control = (G.est == VP_EST_DECOMP && G.trk == VP_TRACK_SPECTRAL) ? 1 : 0;
     k->quant = G.quant; k->epoch = G.epoch; k->global = global ? 1 : 0;
-    const size_t need = (size_t)p->width * p->height * sizeof(float4);
+    const size_t need = (size_t)p->width * p->height * 2 * sizeof(float4);
     if (key != G.crawl_key || !G.d_crawl)
     {
         if (la_quiesce()) return VP_E_NODEVICE;   // batches in flight read the old table
@@ -476,7 +476,12 @@ int ensure_crawl_table(const Param* p, const float4** out)
             S.linear   = 1;
             launch_empty_table(S, p->width, p->height, G.d_danger, G.d_crawl, G.stream);
         }
-        else launch_crawl_table(G.S, G.quant, p->width, p->height, k->control != 0, G.d_crawl, G.stream);
+        else
+        {
+            SceneDev S = G.S;
+            S.linear   = G.linear ? 1 : 0;
+            launch_crawl_table(S, G.quant, p->width, p->height, k->control != 0, G.use_empty_table ? G.d_danger : nullptr, G.d_crawl, G.stream);
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(G.stream));
         G.crawl_key = key;

@@ -65,8 +65,8 @@ struct LaunchDev
     unsigned total_items;  // nframes * ntiles_owned * 64
     float4*  out;          // W*H accumulator (caller-owned)
     float4*  stage;        // [nframes][ntiles_owned*64] per-sample results, or null = accumulate directly
-    const float4* crawl;   // per pixel table or null.  Local-majorant estimators: where the restart crawl in front of the volume
-                           // ends (crawl_table_k); global-majorant estimator: .x = certified-empty distance (empty_table_k)
+    const float4* crawl;   // per pixel two float4, or null: [0] = where the restart crawl in front of the volume ends and its segment /
+                           // draw counts (crawl_table_k, local-majorant estimators), [1].x = certified-empty distance from there
     unsigned* queue;       // VP_NQUEUES sample-queue heads, VP_QUEUE_STRIDE words apart (zeroed before the launch)
     unsigned q_start[VP_NQUEUES + 1];  // slot range [q_start[q], q_start[q+1]) of a frame that queue q hands out
     unsigned long long* counters;  // 6 words (samples, density, bound, opacity, env, scatters) or null
@@ -79,7 +79,8 @@ void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool
                    int blocks, hipStream_t st);
 void launch_env_tables(const float4* env, int w, int h, float* lum, float* row_sum, float* cdf_x, float* cdf_y, float* pdfnorm_alt,
                        hipStream_t st);
-void launch_crawl_table(const SceneDev& S, bool quant, unsigned width, unsigned height, bool control_draw, float4* table, hipStream_t st);
+void launch_crawl_table(const SceneDev& S, bool quant, unsigned width, unsigned height, bool control_draw, const unsigned char* danger, float4* table,
+                        hipStream_t st);
 void launch_danger(const SceneDev& S, bool quant, unsigned char* out, hipStream_t st);
 void launch_empty_table(const SceneDev& S, unsigned width, unsigned height, const unsigned char* danger, float4* table, hipStream_t st);
 void launch_reduce(const LaunchDev& L, hipStream_t st);

@@ -106,8 +106,8 @@ void render_k(SceneDev S, LaunchDev L)
     // scalar tracking only: the sample's extinction coefficient (density, or density * sigma_t[chan]) and its channel
     float    sig_base = density;
     int      chan = 0;
-    // global-majorant estimator: the camera ray is certified to run through empty cells (all eight texels of every fetch
-    // zero) up to this distance from its origin (empty_table_k); 0 once the path has scattered
+    // the unscattered camera ray is certified to run through empty cells (all eight texels of every fetch zero) up to this
+    // distance from the current ray / segment origin (empty_table_k, crawl_table_k); 0 once the path has scattered
     float    t_empty = 0.0f;
     unsigned long long c_load = 0;
 
@@ -436,12 +436,12 @@ void render_k(SceneDev S, LaunchDev L)
                                 rad = f3{0.0f, 0.0f, 0.0f};
                                 nsc = 0;
                                 seg = 0;
-                                if (EST == EST_GLOBAL) t_empty = L.crawl ? L.crawl[(size_t)px + (size_t)py * P.width].x : 0.0f;
+                                t_empty = L.crawl ? L.crawl[2 * ((size_t)px + (size_t)py * P.width) + 1].x : 0.0f;
                                 if (LOCAL && L.crawl)
                                 {
                                     // the restart crawl in front of the volume, done once per pixel by crawl_table_k: the path starts
                                     // where that crawl ends, with its draws skipped and its segments counted
-                                    float4   c = L.crawl[(size_t)px + (size_t)py * P.width];
+                                    float4   c = L.crawl[2 * ((size_t)px + (size_t)py * P.width)];
                                     unsigned k = f2u(c.w);
                                     ro = f3{c.x, c.y, c.z};
                                     rng.skip(k >> 16);
@@ -570,6 +570,7 @@ void render_k(SceneDev S, LaunchDev L)
                         if (through)
                         {
                             ro = ro + rd * t_far;  // tracking restart kernel.cu:2151-2155 / :1809-1813
+                            t_empty -= t_far;      // the certified-empty distance is measured from the segment origin
                             st = ST_SETUP;
                             if (EST == EST_BOUNDED && ++seg >= 800) st = EV_WRITE;  // `continue` still counts, :1716
                         }
@@ -600,8 +601,13 @@ void render_k(SceneDev S, LaunchDev L)
                     }
                     else
                     {
-                        den = sample_density01<QUANT>(S, p) * cur_density;  // vol_sigma_t kernel.cu:682-695
-                        if (COUNT) c_load++;
+                        // local-majorant estimators: the same certificate, measured from the current segment origin
+                        den = 0.0f;
+                        if (shadow || !(dist < t_empty))
+                        {
+                            den = sample_density01<QUANT>(S, p) * cur_density;  // vol_sigma_t kernel.cu:682-695
+                            if (COUNT) c_load++;
+                        }
                     }
                     float e   = rng.next_b();
                     if (COUNT) c_den++;
@@ -743,8 +749,9 @@ void render_k(SceneDev S, LaunchDev L)
 // segments walked (16 bits: the bounded kernel counts them, kernel.cu:1716) and the number of draws they consume (one per
 // segment, one more where the entry brick has a positive minimum and the decomposition estimator draws its control distance,
 // kernel.cu:2048-2054).  A path then starts at the first segment that can interact.  Bit-identical by construction.
+__device__ float certified_empty_distance(const SceneDev& S, f3 ro, f3 rd, const unsigned char* danger);
 template <bool QUANT>
-__global__ __launch_bounds__(256) void crawl_table_k(SceneDev S, unsigned width, unsigned height, int control_draw, float4* table)
+__global__ __launch_bounds__(256) void crawl_table_k(SceneDev S, unsigned width, unsigned height, int control_draw, const unsigned char* danger, float4* table)
 {
     unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= width * height) return;
@@ -752,6 +759,10 @@ __global__ __launch_bounds__(256) void crawl_table_k(SceneDev S, unsigned width,
     f3 ro, rd;
     camera_ray(S, width, height, px, py, ro, rd);
     f3 inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
+    // certified-empty distance of the whole camera ray (see danger_k / certified_empty_distance below), then measured from
+    // where the walk ends: the origins of the restart segments differ from o + d * (walked distance) by the rounding of a
+    // few dozen additions (1e-5), against a safety margin of three quarters of a cell
+    float t_left = S.linear ? certified_empty_distance(S, ro, rd, danger) : 0.0f;
     unsigned segs = 0, draws = 0;
     for (; segs < 700u; segs++)   // far below the bounded kernel's 800-segment cap, and both counts stay within 16 bits
     {
@@ -764,8 +775,10 @@ __global__ __launch_bounds__(256) void crawl_table_k(SceneDev S, unsigned width,
         sample_bound<QUANT>(S, ro + rd * t_near, bx, by);
         draws += (control_draw && by > 0.0f) ? 2u : 1u;
         ro = ro + rd * t_far;
+        t_left -= t_far;
     }
-    table[idx] = make_float4(ro.x, ro.y, ro.z, u2f(segs | (draws << 16)));
+    table[2 * idx]     = make_float4(ro.x, ro.y, ro.z, u2f(segs | (draws << 16)));
+    table[2 * idx + 1] = make_float4(t_left > 0.0f ? t_left : 0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // ---- certified-empty distances of the camera rays (global-majorant estimator).
@@ -801,6 +814,38 @@ __global__ __launch_bounds__(256) void danger_k(SceneDev S, unsigned char* out)
             }
     out[idx] = any ? 1 : 0;
 }
+// distance from the origin up to which the ray (o, d) runs through certified-empty cells; 0 = no certificate
+__device__ float certified_empty_distance(const SceneDev& S, f3 ro, f3 rd, const unsigned char* danger)
+{
+    float t_near, tf;
+    bool  hit = intersect_box(ro, rd, S, t_near, tf);
+    if (!danger || !hit || !(tf == tf) || !(t_near == t_near)) return 0.0f;
+    float t0 = fmaxf(t_near, 0.0f);
+    // a quarter of the smallest cell edge, in world units (the direction is a unit vector)
+    float cell = fminf(fminf((S.bmax[0] - S.bmin[0]) / (float)S.nx, (S.bmax[1] - S.bmin[1]) / (float)S.ny), (S.bmax[2] - S.bmin[2]) / (float)S.nz);
+    float ds   = 0.25f * cell;
+    float t_empty = 1e30f;  // the whole chord is empty unless the march finds otherwise
+    for (unsigned n = 0; n < 200000u; n++)
+    {
+        float tt = t0 + (float)n * ds;
+        if (tt > tf + ds) break;
+        f3    p = to_local(S, ro + rd * tt);
+        int   i, j, k;
+        float w;
+        axis_linear(p.x, S.nx, i, w);
+        axis_linear(p.y, S.ny, j, w);
+        axis_linear(p.z, S.nz, k, w);
+        if (danger[(size_t)i + (size_t)S.nx * ((size_t)j + (size_t)S.ny * k)])
+        {
+            t_empty = fmaxf(tt - 2.0f * ds, 0.0f);
+            break;
+        }
+        if (n == 199999u) t_empty = 0.0f;  // never on a sane scene: no certificate rather than a wrong one
+    }
+    return t_empty > t0 ? t_empty : 0.0f;
+}
+// per pixel two float4: [0] unused here (the local-majorant estimators keep the end of the restart crawl there), [1].x = the
+// certified-empty distance of the camera ray
 __global__ __launch_bounds__(256) void empty_table_k(SceneDev S, unsigned width, unsigned height, const unsigned char* danger, float4* table)
 {
     unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -808,36 +853,8 @@ __global__ __launch_bounds__(256) void empty_table_k(SceneDev S, unsigned width,
     unsigned py = idx / width, px = idx - py * width;
     f3 ro, rd;
     camera_ray(S, width, height, px, py, ro, rd);
-    float t_near, tf;
-    bool  hit = intersect_box(ro, rd, S, t_near, tf);
-    float t_empty = 0.0f;
-    if (hit && tf == tf && t_near == t_near)
-    {
-        float t0 = fmaxf(t_near, 0.0f);
-        // a quarter of the smallest cell edge, in world units (the direction is a unit vector)
-        float cell = fminf(fminf((S.bmax[0] - S.bmin[0]) / (float)S.nx, (S.bmax[1] - S.bmin[1]) / (float)S.ny), (S.bmax[2] - S.bmin[2]) / (float)S.nz);
-        float ds   = 0.25f * cell;
-        t_empty    = 1e30f;  // the whole chord is empty unless the march finds otherwise
-        for (unsigned n = 0; n < 200000u; n++)
-        {
-            float tt = t0 + (float)n * ds;
-            if (tt > tf + ds) break;
-            f3    p = to_local(S, ro + rd * tt);
-            int   i, j, k;
-            float w;
-            axis_linear(p.x, S.nx, i, w);
-            axis_linear(p.y, S.ny, j, w);
-            axis_linear(p.z, S.nz, k, w);
-            if (danger[(size_t)i + (size_t)S.nx * ((size_t)j + (size_t)S.ny * k)])
-            {
-                t_empty = fmaxf(tt - 2.0f * ds, 0.0f);
-                break;
-            }
-            if (n == 199999u) t_empty = 0.0f;  // never on a sane scene: no certificate rather than a wrong one
-        }
-        if (!(t_empty > t0)) t_empty = 0.0f;
-    }
-    table[idx] = make_float4(t_empty, 0.0f, 0.0f, 0.0f);
+    table[2 * idx]     = make_float4(ro.x, ro.y, ro.z, 0.0f);
+    table[2 * idx + 1] = make_float4(certified_empty_distance(S, ro, rd, danger), 0.0f, 0.0f, 0.0f);
 }
 
 // per pixel, add the staged samples in frame order:  acc = (((acc + s0) + s1) + ...)
@@ -1290,11 +1307,12 @@ void launch_env_tables(const float4* env, int w, int h, float* lum, float* row_s
     hipLaunchKernelGGL(env_row_cdf_k, dim3((h + 63) / 64), dim3(64), 0, st, lum, cdf_x, row_sum, w, h);
     hipLaunchKernelGGL(env_col_cdf_k, dim3(1), dim3(64), 0, st, lum, row_sum, cdf_y, pdfnorm_alt, w, h);
 }
-void launch_crawl_table(const SceneDev& S, bool quant, unsigned width, unsigned height, bool control_draw, float4* table, hipStream_t st)
+void launch_crawl_table(const SceneDev& S, bool quant, unsigned width, unsigned height, bool control_draw, const unsigned char* danger, float4* table,
+                        hipStream_t st)
 {
     unsigned n = width * height;
-    if (quant) hipLaunchKernelGGL(crawl_table_k<true>, dim3((n + 255) / 256), dim3(256), 0, st, S, width, height, control_draw ? 1 : 0, table);
-    else hipLaunchKernelGGL(crawl_table_k<false>, dim3((n + 255) / 256), dim3(256), 0, st, S, width, height, control_draw ? 1 : 0, table);
+    if (quant) hipLaunchKernelGGL(crawl_table_k<true>, dim3((n + 255) / 256), dim3(256), 0, st, S, width, height, control_draw ? 1 : 0, danger, table);
+    else hipLaunchKernelGGL(crawl_table_k<false>, dim3((n + 255) / 256), dim3(256), 0, st, S, width, height, control_draw ? 1 : 0, danger, table);
 }
 void launch_danger(const SceneDev& S, bool quant, unsigned char* out, hipStream_t st)
 {
