@@ -989,9 +989,9 @@ int vp_read_counters(vp_counters* out, int reset)
     }
         if (getenv("VP_DEBUG_COUNTERS"))
         {
-            static const char* names[11] = {"setup", "half-step", "lookup+collision", "segment/ray end", "scatter", "nee", "phase", "background", "write", "refill", "global set-up"};
+            static const char* names[12] = {"setup", "half-step", "lookup+collision", "segment/ray end", "scatter", "nee", "phase", "background", "write", "refill", "global set-up", "fetch"};
             fprintf(stderr, "[vp] block: wave executions, lanes per execution (of 64)\n");
-            for (int b = 0; b < 11; b++)
+            for (int b = 0; b < 12; b++)
                 if (h[16 + 2 * b]) fprintf(stderr, "[vp]   %-18s %14llu  %5.1f\n", names[b], h[16 + 2 * b], (double)h[17 + 2 * b] / (double)h[16 + 2 * b]);
         }
     if (reset) HIPCHK(hipMemset(G.d_counters, 0, sizeof h));

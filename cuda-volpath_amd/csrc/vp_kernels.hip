@@ -115,7 +115,7 @@ void render_k(SceneDev S, LaunchDev L)
     unsigned long long d_iter = 0, d_act = 0, d_outer = 0, d_shadow = 0;  // debug (lane 0 counts wave events)
     unsigned long long t_slow = 0, t_fast = 0, t_mark = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;  // shader cycles
     // COUNT build: how often each code block runs (wave executions) and for how many lanes -- where the lane slots go
-    enum { B_SETUP, B_HALF, B_LOOK, B_EXIT, B_SCATTER, B_NEE, B_HG, B_BG, B_WRITE, B_REFILL, B_GSETUP, B_NBLK };
+    enum { B_SETUP, B_HALF, B_LOOK, B_EXIT, B_SCATTER, B_NEE, B_HG, B_BG, B_WRITE, B_REFILL, B_GSETUP, B_FETCH, B_NBLK };
     unsigned long long bw[B_NBLK] = {}, bl[B_NBLK] = {};
     auto tally = [&](int b, bool on) __attribute__((always_inline)) {
         if (COUNT)
@@ -588,6 +588,7 @@ void render_k(SceneDev S, LaunchDev L)
                 {
                     f3    p   = ro + rd * dist;
                     float den;
+                    tally(B_FETCH, shadow || !(dist < t_empty));
                     if (EST == EST_GLOBAL)
                     {
                         // Before t_empty every texel this fetch would filter is zero (empty_table_k): the product is +0 without
