@@ -72,8 +72,6 @@ void render_k(SceneDev S, LaunchDev L)
     }
     constexpr bool LOCAL = EST != EST_GLOBAL;  // the two local-majorant estimators share the segment logic
     const ParamDev& P = L.P;
-    const f3    sun_dir   = f3{S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]};
-    const f3    sun_power = f3{S.sun_power[0], S.sun_power[1], S.sun_power[2]};
     const f3    sig_t     = f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]};
     const f3    sig_s     = sig_t * f3{P.albedo[0], P.albedo[1], P.albedo[2]};
     const float max_sig   = max3(sig_t);
@@ -137,6 +135,18 @@ void render_k(SceneDev S, LaunchDev L)
     {
         if (COUNT && lane == 0) d_outer++;
         // =========================================================== slow path: events
+        // The event section reads its uniforms (camera, sun, environment, queue and image descriptors: ~70 scalars that the
+        // tracking loop never touches) from the kernel-argument segment afresh in every visit -- a few scalar loads that hit
+        // the scalar cache -- instead of holding them in SGPRs across the tracking loop, whose own scalars then fit without
+        // spilling into vector lanes.  The empty asm keeps the compiler from hoisting those loads back out of the loop.
+        {
+        const char* kargs_ = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kargs_));
+        const SceneDev&  S = *reinterpret_cast<const SceneDev*>(kargs_);
+        const LaunchDev& L = *reinterpret_cast<const LaunchDev*>(kargs_ + ((sizeof(SceneDev) + alignof(LaunchDev) - 1) / alignof(LaunchDev)) * alignof(LaunchDev));
+        const ParamDev&  P = L.P;
+        const f3 sun_dir   = f3{S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]};
+        const f3 sun_power = f3{S.sun_power[0], S.sun_power[1], S.sun_power[2]};
         // Tr_spectral set-up kernel.cu:763-780: shadow ray from the collision point ro toward `end`
         auto start_shadow = [&](f3 end, float inv_s, float den) __attribute__((always_inline)) {
             f3    sd = normalize(end - ro);
@@ -492,6 +502,7 @@ void render_k(SceneDev S, LaunchDev L)
             if (__ballot((st == ST_DONE && !exhausted) || st == EV_BG || st == EV_WRITE) == 0ull) break;
         }
         if (__ballot(st != ST_DONE || !exhausted) == 0ull) break;  // queue drained and every lane idle
+        }
         if (COUNT) { unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) t_slow += t - t_mark; t_mark = t; }
 
         // =========================================================== fast path: tracking
