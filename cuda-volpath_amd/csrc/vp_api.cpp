@@ -1037,6 +1037,21 @@ int vp_get_bound_table(void* dst, size_t bytes, int* bnx, int* bny, int* bnz, in
     }
     return VP_OK;
 }
+int vp_get_pixel_table(const Param* p, float* dst, size_t count)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !dst) return fail(VP_E_ARG, "vp_get_pixel_table: null argument");
+    if (!G.have_volume || !G.have_cam) return fail(VP_E_STATE, "vp_get_pixel_table needs a volume and a camera");
+    const size_t need = (size_t)p->width * p->height * 8;
+    if (count < need) return fail(VP_E_ARG, "pixel table needs %zu floats", need);
+    const float4* t = nullptr;
+    rc = ensure_crawl_table(p, &t);
+    if (rc) return rc;
+    if (!t) return fail(VP_E_STATE, "no pixel table in this configuration (point filtering, or the tables are switched off)");
+    HIPCHK(hipMemcpy(dst, t, need * sizeof(float), hipMemcpyDeviceToHost));
+    return VP_OK;
+}
 int vp_get_opacity(float* dst, size_t count)
 {
     if (!G.d_opacity) return fail(VP_E_STATE, "no opacity table");

@@ -193,6 +193,11 @@ int vp_render_time_ms(double* total_ms, int* launches, int reset);
 /* the derived tables, for tests: bound table dims/brick and a device->host copy */
 int vp_get_bound_table(void* dst, size_t bytes, int* bnx, int* bny, int* bnz, int* brick, int* radius);
 int vp_get_opacity(float* dst, size_t count);
+/* the per-pixel table of the current estimator / camera / volume for a width x height image, 8 floats per pixel:
+ * [0..2] where the restart crawl in front of the volume ends (local-majorant estimators; the camera origin otherwise),
+ * [3] its segment and draw counts (bits: segments | draws << 16), [4] the distance from there up to which the camera ray is
+ * certified to meet only empty cells, [5..7] unused.  Test hook for the certificates. */
+int vp_get_pixel_table(const Param* p, float* dst, size_t count);
 
 /* building blocks exposed for parity tests (device execution, host arrays) */
 int vp_test_math(int which, const float* in, float* out, int n);
