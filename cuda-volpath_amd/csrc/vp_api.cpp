@@ -87,6 +87,19 @@ struct State
     // where the restart crawl in front of the volume ends, per pixel (crawl_table_k); rebuilt when what it depends on changes
     bool        use_crawl_table = true;
     bool        use_empty_table = true;   // global-majorant estimator: certified-empty distances of the camera rays
+    bool        use_light   = true;       // ... and the light kernel for tiles whose rays all meet empty cells only
+    // the pixels this context owns (those of its tiles), class by class: [general..., light...], each y << 16 | x
+    unsigned*   d_tiles     = nullptr;
+    size_t      tiles_cap   = 0;
+    unsigned    n_general   = 0, n_light = 0;
+    std::vector<unsigned char> tiles_key;
+    // the light kernel runs beside the general one on a stream of its own (ALU-bound waves fill the issue slots the general
+    // kernel's waves leave while they wait for cells): one auxiliary stream and two events per launch target
+    bool        light_overlap = true;
+    hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t  aux_ev[3][2]  = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    // resident 256-thread workgroups per CU while both kernels run: 3 + 4 measured best on C2 (profiles/r02_light_overlap.txt)
+    unsigned    general_blocks_per_cu = 3, light_blocks_per_cu = 4;
     unsigned char* d_danger = nullptr;    // per cell: a non-empty cell within its 3x3x3 neighbourhood (danger_k)
     float4*     d_crawl     = nullptr;
     size_t      crawl_bytes = 0;
@@ -161,7 +174,7 @@ int ensure_device()
     G.num_cu = prop.multiProcessorCount;
     HIPCHK(hipStreamCreateWithFlags(&G.own_stream, hipStreamNonBlocking));
     if (!G.stream) G.stream = G.own_stream;
-    HIPCHK(hipMalloc((void**)&G.d_queue, 3 * kQueueWords * sizeof(unsigned)));  // caller's stream + two look-ahead slots
+    HIPCHK(hipMalloc((void**)&G.d_queue, 6 * kQueueWords * sizeof(unsigned)));  // (caller's stream + two look-ahead slots) x two tile classes
     HIPCHK(hipMalloc((void**)&G.d_counters, kCounterWords * sizeof(unsigned long long)));
     HIPCHK(hipMemset(G.d_counters, 0, kCounterWords * sizeof(unsigned long long)));
     G.S.sun_cos = 94.0f / sqrtf(94.0f * 94.0f + 0.45f * 0.45f);                    // kernel.cu:1263
@@ -191,6 +204,10 @@ int ensure_device()
     if (knob("VP_NO_LDS_BOUNDS", 0, 1, v)) G.use_lds_bounds = v == 0;
     if (knob("VP_NO_CRAWL_TABLE", 0, 1, v)) G.use_crawl_table = v == 0;
     if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;
+    if (knob("VP_NO_LIGHT", 0, 1, v)) G.use_light = v == 0;
+    if (knob("VP_NO_LIGHT_OVERLAP", 0, 1, v)) G.light_overlap = v == 0;
+    if (knob("VP_GENERAL_BLOCKS_PER_CU", 1, 8, v)) G.general_blocks_per_cu = (unsigned)v;
+    if (knob("VP_LIGHT_BLOCKS_PER_CU", 1, 8, v)) G.light_blocks_per_cu = (unsigned)v;
     if (knob("VP_LOOKAHEAD", 0, 4096, v)) G.la_max = (int)v;
     G.dev_ready = true;
     return VP_OK;
@@ -409,16 +426,25 @@ void trim_events()
     }
 }
 
-// the tile slots of this context's shard (include/volpath.h vp_tile_owner; vp_kernels.h owned_tile)
-struct Shard { unsigned tiles_x, tiles_y, tiles_per_row, owned; size_t per_frame; };
+// the shard of this context (include/volpath.h vp_tile_owner): its 8x8 tiles and the pixels of the image they hold
+struct Shard { unsigned tiles_x, tiles_y, owned; size_t per_frame; };  // owned = tiles, per_frame = pixels = samples per frame
 Shard shard_of(const Param* p)
 {
     Shard s;
-    s.tiles_x       = (p->width + 7) / 8;
-    s.tiles_y       = (p->height + 7) / 8;
-    s.tiles_per_row = (s.tiles_x + G.world - 1) / G.world;
-    s.owned         = s.tiles_per_row * s.tiles_y;
-    s.per_frame     = (size_t)s.owned * 64;
+    s.tiles_x = (p->width + 7) / 8;
+    s.tiles_y = (p->height + 7) / 8;
+    s.owned   = 0;
+    s.per_frame = 0;
+    for (unsigned ty = 0; ty < s.tiles_y; ty++)
+    {
+        const unsigned rows = std::min(8u, p->height - ty * 8u);
+        // tiles tx of this row with (tx + shift) % world == rank
+        for (unsigned tx = (G.rank + G.world - tile_row_shift(ty, G.world)) % G.world; tx < s.tiles_x; tx += G.world)
+        {
+            s.owned++;
+            s.per_frame += (size_t)rows * std::min(8u, p->width - tx * 8u);
+        }
+    }
     return s;
 }
 // frames of per_frame samples one staged launch may hold: the configured cap, a quarter of the memory that is free
@@ -490,8 +516,61 @@ int ensure_crawl_table(const Param* p, const float4** out)
     return VP_OK;
 }
 
+// The pixel lists of this context: the pixels of its tiles, tile by tile (row-major tiles, row-major pixels within a tile: the
+// order keeps the rays of a wave in one pencil of the volume), general pixels first, then the light class (global-majorant
+// estimator with spectral tracking: camera rays that miss the box or meet certified-empty cells over their whole chord --
+// pixel_class_k over the pixel table).  Rebuilt when the image size, the shard or the table changes.
+int ensure_pixel_lists(const Param* p, const float4* table, const Shard& sh)
+{
+    const bool light = G.use_light && table && G.est == VP_EST_GLOBAL && G.trk == VP_TRACK_SPECTRAL;
+    struct K { unsigned w, h, rank, world; int light; };
+    std::vector<unsigned char> key(sizeof(K), 0);
+    K* k = reinterpret_cast<K*>(key.data());
+    k->w = p->width; k->h = p->height; k->rank = G.rank; k->world = G.world; k->light = light ? 1 : 0;
+    if (light) key.insert(key.end(), G.crawl_key.begin(), G.crawl_key.end());
+    if (key == G.tiles_key && G.d_tiles) return VP_OK;
+    if (la_quiesce()) return VP_E_NODEVICE;   // batches in flight read the old lists
+    HIPCHK(hipStreamSynchronize(G.stream));
+    const unsigned npix = p->width * p->height;
+    std::vector<unsigned char> cls(npix, 0);
+    if (light)
+    {
+        unsigned char* d_cls = nullptr;
+        HIPCHK(hipMalloc((void**)&d_cls, npix));
+        launch_pixel_classes(table, npix, d_cls, G.stream);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(cls.data(), d_cls, npix, hipMemcpyDeviceToHost, G.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(G.stream);
+        (void)hipFree(d_cls);
+        if (e != hipSuccess) return fail(VP_E_NODEVICE, "pixel classes -> %s", hipGetErrorString(e));
+    }
+    std::vector<unsigned> general, lightv;
+    general.reserve(sh.per_frame);
+    for (unsigned ty = 0; ty < sh.tiles_y; ty++)
+        for (unsigned tx = (G.rank + G.world - tile_row_shift(ty, G.world)) % G.world; tx < sh.tiles_x; tx += G.world)
+            for (unsigned y = ty * 8u; y < ty * 8u + 8u && y < p->height; y++)
+                for (unsigned x = tx * 8u; x < tx * 8u + 8u && x < p->width; x++)
+                    (cls[(size_t)y * p->width + x] ? lightv : general).push_back(y << 16 | x);
+    G.n_general = (unsigned)general.size(); G.n_light = (unsigned)lightv.size();
+    general.insert(general.end(), lightv.begin(), lightv.end());
+    if (general.size() > G.tiles_cap)
+    {
+        if (G.d_tiles) HIPCHK(hipFree(G.d_tiles));
+        G.d_tiles = nullptr; G.tiles_cap = 0; G.tiles_key.clear();
+        HIPCHK(hipMalloc((void**)&G.d_tiles, general.size() * sizeof(unsigned)));
+        G.tiles_cap = general.size();
+    }
+    if (!general.empty())
+    {
+        HIPCHK(hipMemcpyAsync(G.d_tiles, general.data(), general.size() * sizeof(unsigned), hipMemcpyHostToDevice, G.stream));
+        HIPCHK(hipStreamSynchronize(G.stream));
+    }
+    G.tiles_key = key;
+    return VP_OK;
+}
+
 // where a render launch goes: the caller's stream with the shared staging buffer, or a look-ahead slot
-struct Target { hipStream_t stream; float4** stage; size_t* stage_bytes; unsigned* queue; };
+struct Target { hipStream_t stream; float4** stage; size_t* stage_bytes; unsigned* queue; int index; };
 
 int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool stage_only = false, const Target* tgt = nullptr)
 {
@@ -502,7 +581,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     if (!G.have_sun) return fail(VP_E_STATE, "render before set_sun");
     if (!G.have_cam) return fail(VP_E_STATE, "render before copy_inv_view_matrix");
     if (!d_out || !p || nframes <= 0 || first < 0) return fail(VP_E_ARG, "bad render arguments");
-    const Target main_tgt = {G.stream, &G.d_stage, &G.stage_bytes, G.d_queue};
+    const Target main_tgt = {G.stream, &G.d_stage, &G.stage_bytes, G.d_queue, 0};
     const Target& T = tgt ? *tgt : main_tgt;
     if (p->width == 0 || p->height == 0 || p->width > 65535 || p->height > 65535)
         return fail(VP_E_ARG, "image %ux%u out of range (sampler.h packs x<<16|y)", p->width, p->height);
@@ -516,21 +595,18 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     static_assert(sizeof(ParamDev) == sizeof(Param) && sizeof(Param) == 44, "Param layout (param.h:4-12)");
     memcpy(&L.P, p, sizeof(Param));
     const Shard sh = shard_of(p);
-    L.tiles_x = sh.tiles_x; L.tiles_y = sh.tiles_y; L.tiles_per_row = sh.tiles_per_row;
-    L.rank = G.rank; L.world = G.world;
-    L.ntiles_owned = sh.owned;
     L.out = (float4*)d_out;
-    L.queue = T.queue;
     L.counters = G.count ? G.d_counters : nullptr;
     L.key0 = G.key0; L.key1 = G.key1;
     L.wait_lanes = G.wait_lanes; L.wait_iters = G.wait_iters; L.setup_lanes = G.setup_lanes;
-    if (L.ntiles_owned == 0) return VP_OK;
+    if (sh.per_frame == 0) return VP_OK;
     rc = ensure_crawl_table(p, &L.crawl);
+    if (rc) return rc;
+    rc = ensure_pixel_lists(p, L.crawl, sh);
     if (rc) return rc;
     const size_t per_frame = sh.per_frame;
     if (0xfffffff0u / per_frame < 1) return fail(VP_E_ARG, "image too large for the 32-bit sample queue");
-    // the owned tile slots (row-major) split into VP_NQUEUES bands of whole tiles
-    for (unsigned q = 0; q <= VP_NQUEUES; q++) L.q_start[q] = (unsigned)((unsigned long long)L.ntiles_owned * q / VP_NQUEUES) * 64u;
+    L.stage_stride = (unsigned)per_frame;
     size_t max_f = (nframes > 1 || stage_only) ? stage_frames_cap(per_frame, *T.stage_bytes) : 1;
     SceneDev S = G.S;
     S.linear   = G.linear ? 1 : 0;
@@ -540,7 +616,6 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         if (stage_only && f != nframes) return fail(VP_E_ARG, "look-ahead batch does not fit the staging buffer");
         L.frame0 = first + done;
         L.nframes = f;
-        L.total_items = (unsigned)(per_frame * (size_t)f);
         if (f > 1 || stage_only)
         {
             size_t need = per_frame * (size_t)f * sizeof(float4);
@@ -565,24 +640,69 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         }
         else
             L.stage = nullptr;
-        HIPCHK(hipMemsetAsync(T.queue, 0, kQueueWords * sizeof(unsigned), T.stream));
+        HIPCHK(hipMemsetAsync(T.queue, 0, 2 * kQueueWords * sizeof(unsigned), T.stream));
         // the brick table goes through LDS when it fits (decomposition estimator, byte table <= 64 KiB)
         const bool lds_bounds = G.use_lds_bounds && G.est == VP_EST_DECOMP && G.quant && !G.env_mis && !G.trk &&
                                 (size_t)S.bnx * S.bny * S.bnz <= (size_t)VP_LDS_BOUND_ENTRIES;
-        const unsigned bsz = lds_bounds ? VP_BLOCK_LDS : VP_BLOCK;
-        unsigned waves  = (L.total_items + 63) / 64;
-        unsigned blocks = (waves + (bsz / 64) - 1) / (bsz / 64);
-        unsigned cap    = (unsigned)G.num_cu * (lds_bounds ? 2u : G.blocks_per_cu);
-        if (blocks > cap) blocks = cap;
         hipEvent_t e0 = get_event(), e1 = get_event();
         bool timed = e0 && e1 && hipEventRecord(e0, T.stream) == hipSuccess;
-        launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, G.trk, (int)blocks, T.stream);
-        hipError_t le = hipGetLastError();
+        hipError_t le = hipSuccess;
+        // one launch per pixel class: the general pixels, then the light ones (their own kernel, their own sample queues)
+        for (int cls = 0; cls < 2 && le == hipSuccess; cls++)
+        {
+            const unsigned nt = cls ? G.n_light : G.n_general;
+            if (!nt) continue;
+            L.pixels      = G.d_tiles + (cls ? G.n_general : 0);
+            L.nslots      = nt;
+            L.slot_base   = cls ? G.n_general : 0u;
+            L.total_items = (unsigned)((size_t)nt * (size_t)f);
+            L.queue       = T.queue + (cls ? kQueueWords : 0);
+            // the pixels of the class split into VP_NQUEUES bands (whole 64-pixel groups, the last band takes the rest)
+            for (unsigned q = 0; q <= VP_NQUEUES; q++) L.q_start[q] = q == VP_NQUEUES ? nt : (unsigned)((unsigned long long)(nt / 64u) * q / VP_NQUEUES) * 64u;
+            const bool     ldsb = lds_bounds && !cls;
+            const unsigned bsz  = ldsb ? VP_BLOCK_LDS : VP_BLOCK;
+            unsigned waves  = (L.total_items + 63) / 64;
+            unsigned blocks = (waves + (bsz / 64) - 1) / (bsz / 64);
+            const bool     both = G.n_light && G.n_general;
+            unsigned       bpc  = G.blocks_per_cu;
+            if (both && cls && G.light_blocks_per_cu) bpc = G.light_blocks_per_cu;
+            if (both && !cls && G.general_blocks_per_cu) bpc = G.general_blocks_per_cu;
+            unsigned cap    = (unsigned)G.num_cu * (ldsb ? 2u : bpc);
+            if (blocks > cap) blocks = cap;
+            if (cls)
+            {
+                // the light kernel: beside the general one on the target's auxiliary stream when both classes have work
+                hipStream_t ls = T.stream;
+                if (both && G.light_overlap)
+                {
+                    const int ti = T.index;
+                    if (!G.aux_stream[ti] && hipStreamCreateWithFlags(&G.aux_stream[ti], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); G.aux_stream[ti] = nullptr; }
+                    for (int q = 0; q < 2; q++)
+                        if (!G.aux_ev[ti][q] && hipEventCreateWithFlags(&G.aux_ev[ti][q], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G.aux_ev[ti][q] = nullptr; }
+                    if (G.aux_stream[ti] && G.aux_ev[ti][0] && G.aux_ev[ti][1] && e0 && hipStreamWaitEvent(G.aux_stream[ti], e0, 0) == hipSuccess) ls = G.aux_stream[ti];
+                }
+                launch_render_light(S, L, G.rng, G.count, (int)blocks, ls);
+                le = hipGetLastError();
+                if (ls != T.stream && le == hipSuccess)
+                {
+                    // the target stream goes on (end-of-launch event, add-kernel) only when the light kernel is done too
+                    if (hipEventRecord(G.aux_ev[T.index][1], ls) != hipSuccess || hipStreamWaitEvent(T.stream, G.aux_ev[T.index][1], 0) != hipSuccess)
+                        le = hipGetLastError();
+                }
+            }
+            else
+            {
+                launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, G.trk, (int)blocks, T.stream);
+                le = hipGetLastError();
+            }
+        }
         timed = timed && le == hipSuccess && hipEventRecord(e1, T.stream) == hipSuccess;
         G.timed_n++;
         if (timed) { G.events.emplace_back(e0, e1); trim_events(); }
         else { put_event(e0); put_event(e1); }
         if (le != hipSuccess) return fail(VP_E_NODEVICE, "render launch -> %s", hipGetErrorString(le));
+        // for the add-kernel: all tiles of the rank
+        L.pixels = G.d_tiles; L.nslots = (unsigned)per_frame; L.slot_base = 0;
         if (L.stage && !stage_only)
         {
             launch_reduce(L, T.stream);
@@ -634,7 +754,7 @@ int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, c
     HIPCHK(hipEventRecord(ev, G.stream));
     HIPCHK(hipStreamWaitEvent(s.stream, ev, 0));
     put_event(ev);
-    const Target t = {s.stream, &s.buf, &s.bytes, G.d_queue + kQueueWords * (si + 1)};
+    const Target t = {s.stream, &s.buf, &s.bytes, G.d_queue + 2 * kQueueWords * (si + 1), si + 1};
     int rc = do_render(d_out, first, n, p, true, &t);
     if (rc) return rc;
     HIPCHK(hipEventRecord(s.done, s.stream));
@@ -674,8 +794,7 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
         HIPCHK(hipStreamWaitEvent(G.stream, s.done, 0));
         LaunchDev L = {};
         memcpy(&L.P, p, sizeof(Param));
-        L.tiles_x = sh.tiles_x; L.tiles_y = sh.tiles_y; L.tiles_per_row = sh.tiles_per_row;
-        L.rank = G.rank; L.world = G.world; L.ntiles_owned = sh.owned;
+        L.pixels = G.d_tiles; L.nslots = (unsigned)per_frame; L.stage_stride = (unsigned)per_frame;
         L.out = (float4*)d_out;
         L.stage = s.buf + (size_t)(frame - s.first) * per_frame;
         L.nframes = 1;
@@ -866,6 +985,12 @@ int vp_ctx_destroy(vp_ctx* ctx)
         for (auto e : D.event_pool) (void)hipEventDestroy(e);
         if (D.d_stage) (void)hipFree(D.d_stage);
         if (D.d_crawl) (void)hipFree(D.d_crawl);
+        if (D.d_tiles) (void)hipFree(D.d_tiles);
+        for (int i = 0; i < 3; i++)
+        {
+            if (D.aux_stream[i]) { (void)hipStreamSynchronize(D.aux_stream[i]); (void)hipStreamDestroy(D.aux_stream[i]); }
+            for (int q = 0; q < 2; q++) if (D.aux_ev[i][q]) (void)hipEventDestroy(D.aux_ev[i][q]);
+        }
         if (D.d_queue) (void)hipFree(D.d_queue);
         if (D.d_counters) (void)hipFree(D.d_counters);
         if (D.own_stream) (void)hipStreamDestroy(D.own_stream);

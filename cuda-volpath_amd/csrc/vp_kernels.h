@@ -40,43 +40,43 @@
 namespace vp
 {
 // Pixel-tile deal (include/volpath.h vp_tile_owner): tile (tx, ty) belongs to rank (tx + tile_row_shift(ty)) % world, i.e.
-// within a tile row every world-th tile, rows shifted against each other by a hash of the row index.  Slot `ot` of a rank
-// is its (ot % tiles_per_row)-th tile of row ot / tiles_per_row; slots past the row's end (tx >= tiles_x) are padding.
+// within a tile row every world-th tile, rows shifted against each other by a hash of the row index.  The host lists a rank's
+// tiles (vp_api.cpp tile lists); the kernels read the list.
 __host__ __device__ inline unsigned tile_row_shift(unsigned ty, unsigned world) { return ((ty * 0x9E3779B1u) >> 15) % world; }
-__host__ __device__ inline void owned_tile(unsigned ot, unsigned tiles_per_row, unsigned rank, unsigned world, unsigned& tx, unsigned& ty)
-{
-    ty         = ot / tiles_per_row;
-    unsigned j = ot - ty * tiles_per_row;
-    tx         = j * world + (rank + world - tile_row_shift(ty, world)) % world;
-}
-
 // same values as the VP_EST_* / VP_RNG_* enums of include/volpath.h
 constexpr int EST_GLOBAL = 0, EST_DECOMP = 1, EST_BOUNDED = 2;
 constexpr int RNG_SAMPLERH = 0, RNG_PHILOX = 1, RNG_PHILOX7 = 2;
 
-// one render launch: frames [frame0, frame0+nframes) x the 8x8 pixel tiles this rank owns
+// one render launch: frames [frame0, frame0+nframes) x a list of pixels (one class of the pixels this rank owns)
 struct LaunchDev
 {
     ParamDev P;
     int      frame0, nframes;
-    unsigned tiles_x, tiles_y;
-    unsigned tiles_per_row;  // owned tile slots per tile row: ceil(tiles_x / world); slots beyond the row's end are padding
-    unsigned ntiles_owned, rank, world;  // ntiles_owned = tiles_per_row * tiles_y (padding included)
-    unsigned total_items;  // nframes * ntiles_owned * 64
-    float4*  out;          // W*H accumulator (caller-owned)
-    float4*  stage;        // [nframes][ntiles_owned*64] per-sample results, or null = accumulate directly
-    const float4* crawl;   // per pixel two float4, or null: [0] = where the restart crawl in front of the volume ends and its segment /
-                           // draw counts (crawl_table_k, local-majorant estimators), [1].x = certified-empty distance from there
-    unsigned* queue;       // VP_NQUEUES sample-queue heads, VP_QUEUE_STRIDE words apart (zeroed before the launch)
+    unsigned nslots;        // pixels of THIS launch (its slice of the pixel list) = samples per frame
+    unsigned total_items;   // nframes * nslots
+    const unsigned* pixels; // pixel of slot s: pixels[s] = y << 16 | x.  The rank's pixels (those of its 8x8 tiles, tile by tile) are
+                            // listed class by class: general pixels, then "light" pixels whose camera ray meets empty cells only;
+                            // a launch covers one class
+    unsigned stage_stride;  // samples per frame in `stage`, all classes together
+    unsigned slot_base;     // first sample slot of this launch's class within a frame of `stage`
+    float4*  out;           // W*H accumulator (caller-owned)
+    float4*  stage;         // [nframes][stage_stride] per-sample results, or null = accumulate directly
+    const float4* crawl;    // per pixel two float4, or null: [0] = where the restart crawl in front of the volume ends and its segment /
+                            // draw counts (crawl_table_k, local-majorant estimators), [1].x = certified-empty distance from there,
+                            // [1].y = pixel class (0 general, 1 the whole chord is certified empty, 2 the ray misses the box)
+    unsigned* queue;        // VP_NQUEUES sample-queue heads, VP_QUEUE_STRIDE words apart (zeroed before the launch)
     unsigned q_start[VP_NQUEUES + 1];  // slot range [q_start[q], q_start[q+1]) of a frame that queue q hands out
-    unsigned long long* counters;  // 6 words (samples, density, bound, opacity, env, scatters) or null
-    unsigned key0, key1;   // Philox key
+    unsigned long long* counters;  // work counters, loop statistics and block tallies (vp_api.cpp kCounterWords) or null
+    unsigned key0, key1;    // Philox key
     unsigned wait_lanes, wait_iters;  // inner-loop exit policy (VP_WAIT_LANES / VP_WAIT_ITERS)
-    unsigned setup_lanes;  // lanes that must ask for a segment set-up before it runs mid-pass (VP_SETUP_LANES; 1 = at every step)
+    unsigned setup_lanes;   // lanes that must ask for a segment set-up before it runs mid-pass (VP_SETUP_LANES; 1 = at every step)
 };
 
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
                    int blocks, hipStream_t st);
+// the light class of the global-majorant estimator (spectral tracking): tiles whose camera rays meet empty cells only
+void launch_render_light(const SceneDev& S, const LaunchDev& L, int rng, bool count, int blocks, hipStream_t st);
+void launch_pixel_classes(const float4* table, unsigned npixels, unsigned char* out, hipStream_t st);
 void launch_env_tables(const float4* env, int w, int h, float* lum, float* row_sum, float* cdf_x, float* cdf_y, float* pdfnorm_alt,
                        hipStream_t st);
 void launch_crawl_table(const SceneDev& S, bool quant, unsigned width, unsigned height, bool control_draw, const unsigned char* danger, float4* table,

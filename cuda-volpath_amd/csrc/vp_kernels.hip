@@ -52,7 +52,10 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
 // build, kernel.cu:2220-2297); the shipped configuration is passive (MIS = false).
 // TRK: 0 = spectral tracking (SPECTRAL_TRACKING 1, the shipped build); 1 = scalar tracking (SPECTRAL_TRACKING 0);
 // 2 = MULTI_CHANNEL 1: scalar tracking of one colour channel drawn per sample (kernel.cu:15-34, :1993-1994, :2311-2313).
-template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool MIS, int TRK>
+// LIGHT: the kernel of the "light" pixel class (global-majorant estimator, spectral tracking): every camera ray of those pixels
+// either misses the box or meets certified-empty cells over its whole chord (empty_table_k), so a path is: free-flight steps
+// whose null collisions have den = +0 folded in, then the environment.  No fetch code, no collision, shadow or phase states.
+template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool MIS, int TRK, bool LIGHT = false>
 // The local-majorant kernels need 98 VGPRs when left alone, two more than five waves per SIMD allow (512 / 5 -> 96):
 // asking for five costs no spill and is +10 % on the reference-table decomposition workload.  The global-majorant
 // kernel fits six waves (80 VGPRs, no spill): +3 % now that the queue order keeps the L2 hit rate above 90 %.
@@ -81,7 +84,7 @@ void render_k(SceneDev S, LaunchDev L)
     // ---- per-lane path state
     int      st = ST_DONE;
     bool     exhausted = false;
-    unsigned item = 0;           // queue index of the sample this lane works on
+    unsigned item = 0;           // where this lane's sample goes in the staging buffer
     unsigned px = 0, py = 0;
     int      frame = 0;
     RNG      rng;
@@ -125,7 +128,7 @@ void render_k(SceneDev S, LaunchDev L)
 
     const unsigned lane = threadIdx.x & 63u;
     unsigned chunk_next = 0, chunk_end = 0;  // wave-uniform
-    unsigned chunk_base = 0, chunk_fl = 0, chunk_ot0 = 0, chunk_ty0 = 0, chunk_j0 = 0;  // of the current chunk (wave-uniform)
+    unsigned chunk_base = 0, chunk_fl = 0, chunk_stage = 0;  // of the current chunk (wave-uniform)
     bool     queue_empty = false;
     // the queue this wave draws from: its XCD's first (HW_REG_XCC_ID, bits 3:0), then the others in turn
     unsigned q_cur   = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & (VP_NQUEUES - 1);
@@ -191,7 +194,7 @@ void render_k(SceneDev S, LaunchDev L)
         };
         // ---- collision: direct lighting set-up (kernel.cu:2161-2217 / :1458-1491)
         tally(B_SCATTER, st == EV_SCATTER);
-        if (st == EV_SCATTER)
+        if (!LIGHT && st == EV_SCATTER)
         {
             if (COUNT) c_sca++;
             t_empty = 0.0f;  // the certificate is for the unscattered camera ray only
@@ -257,7 +260,7 @@ void render_k(SceneDev S, LaunchDev L)
         {
             // ---- a light estimate is complete (kernel.cu:2188-2189,:2209-2210 and :2254,:2290)
             tally(B_NEE, st == EV_NEE);
-            if (st == EV_NEE)
+            if (!LIGHT && st == EV_NEE)
             {
                 if (MIS)
                 {
@@ -321,7 +324,7 @@ void render_k(SceneDev S, LaunchDev L)
         }
         // ---- phase-function sampling (kernel.cu:2301-2303)
         tally(B_HG, st == EV_HG);
-        if (st == EV_HG)
+        if (!LIGHT && st == EV_HG)
         {
             Frame fr(pd);
             float r0 = rng.next_a();
@@ -392,15 +395,13 @@ void render_k(SceneDev S, LaunchDev L)
                         if (c < cpf * (unsigned)L.nframes)
                         {
                             const unsigned pos = c / (unsigned)L.nframes, fl = c - pos * (unsigned)L.nframes, off = pos * (unsigned)VP_CHUNK;
-                            chunk_base = fl * (L.ntiles_owned * 64u);
+                            chunk_base = fl * (L.nslots);
                             chunk_next = chunk_base + q0 + off;
                             chunk_end  = chunk_next + (len - off < (unsigned)VP_CHUNK ? len - off : (unsigned)VP_CHUNK);
-                            // the chunk lies in ONE frame and covers a few consecutive tile slots: its frame and the tile row /
-                            // column of its first slot are found once here, so that a refill needs no integer division per lane
-                            chunk_fl   = fl;
-                            chunk_ot0  = (q0 + off) >> 6;
-                            chunk_ty0  = chunk_ot0 / L.tiles_per_row;
-                            chunk_j0   = chunk_ot0 - chunk_ty0 * L.tiles_per_row;
+                            // the chunk lies in ONE frame: its frame and where that frame's samples of this class start in the
+                            // staging buffer are found once here (no integer division per lane in a refill)
+                            chunk_fl    = fl;
+                            chunk_stage = fl * L.stage_stride + L.slot_base;
                         }
                         else
                         {
@@ -418,18 +419,11 @@ void render_k(SceneDev S, LaunchDev L)
                         if (rank >= take) { if (queue_empty) exhausted = true; /* else: next chunk, next round */ }
                         else
                         {
-                            item = chunk_next + rank;
-                            unsigned rem = item - chunk_base;          // slot within the frame
-                            unsigned ot  = rem >> 6, w = rem & 63u;
-                            // owned_tile(ot, ...) from the chunk's first slot: at most VP_CHUNK / 64 slots further on
-                            unsigned j = chunk_j0 + (ot - chunk_ot0), ty = chunk_ty0;
-#pragma unroll
-                            for (int k = 0; k < VP_CHUNK / 64; k++)
-                                if (j >= L.tiles_per_row) { j -= L.tiles_per_row; ty++; }
-                            unsigned tx = j;
-                            if (L.world > 1) tx = j * L.world + (L.rank + L.world - tile_row_shift(ty, L.world)) % L.world;
-                            px    = tx * 8u + (w & 7u);
-                            py    = ty * 8u + (w >> 3);
+                            unsigned rem = chunk_next + rank - chunk_base;  // sample slot of this class within the frame
+                            item = chunk_stage + rem;
+                            unsigned pix = L.pixels[rem];
+                            px    = pix & 0xffffu;
+                            py    = pix >> 16;
                             frame = L.frame0 + (int)chunk_fl;
                             if (px < P.width && py < P.height)
                             {
@@ -446,7 +440,7 @@ void render_k(SceneDev S, LaunchDev L)
                                 rad = f3{0.0f, 0.0f, 0.0f};
                                 nsc = 0;
                                 seg = 0;
-                                t_empty = L.crawl ? L.crawl[2 * ((size_t)px + (size_t)py * P.width) + 1].x : 0.0f;
+                                if (!LIGHT) t_empty = L.crawl ? L.crawl[2 * ((size_t)px + (size_t)py * P.width) + 1].x : 0.0f;
                                 if (LOCAL && L.crawl)
                                 {
                                     // the restart crawl in front of the volume, done once per pixel by crawl_table_k: the path starts
@@ -561,6 +555,39 @@ void render_k(SceneDev S, LaunchDev L)
         };
         auto tracking_step = [&]() __attribute__((always_inline)) {
             tally(B_HALF, st == ST_TRACK || st == ST_SHADOW);
+            if (LIGHT)
+            {
+                // Every fetch of this path would filter eight zero texels (certified: the whole chord): the general expressions
+                // below with den = +0 reduce exactly to sigma_t_den = +0, Ps = +0, c = Pn, `real` false for any draw and
+                // sigma_null_den = sigma_t_prime -- no position, fetch or filter.  (A throughput that is not
+                // finite stays NaN either way and the sample is written as 0.)
+                if (st == ST_TRACK)
+                {
+                    dist += -logf_(rng.next_a()) * inv_sigma;  // kernel.cu:1419
+                    if (dist >= t_end) st = EV_BG;              // transmitted through the box kernel.cu:1444-1452
+                    else
+                    {
+                        // the collision test's variate is not needed (`real` is false whatever it is), but a sequential stream
+                        // (sampler.h) must still move past it; for the counter-based streams this is nothing
+                        (void)rng.next_b();
+                        if (COUNT) c_den++;
+                        if (ACH)
+                        {
+                            float mn = __builtin_fabsf(sigma_t_prime * thr.x);
+                            float Pn = (mn + mn) + mn;
+                            thr.x    = thr.x * (sigma_t_prime * wdiv_(inv_sigma_t * Pn, Pn));
+                        }
+                        else
+                        {
+                            float Pn = __builtin_fabsf(sigma_t_prime * thr.x) + __builtin_fabsf(sigma_t_prime * thr.y) +
+                                       __builtin_fabsf(sigma_t_prime * thr.z);
+                            float sf = sigma_t_prime * wdiv_(inv_sigma_t * Pn, Pn);
+                            thr      = thr * f3{sf, sf, sf};
+                        }
+                    }
+                }
+                return;
+            }
             if (st == ST_TRACK || st == ST_SHADOW)
             {
                 const bool shadow = st == ST_SHADOW;
@@ -761,7 +788,7 @@ void render_k(SceneDev S, LaunchDev L)
 // segments walked (16 bits: the bounded kernel counts them, kernel.cu:1716) and the number of draws they consume (one per
 // segment, one more where the entry brick has a positive minimum and the decomposition estimator draws its control distance,
 // kernel.cu:2048-2054).  A path then starts at the first segment that can interact.  Bit-identical by construction.
-__device__ float certified_empty_distance(const SceneDev& S, f3 ro, f3 rd, const unsigned char* danger);
+__device__ float certified_empty_distance(const SceneDev& S, f3 ro, f3 rd, const unsigned char* danger, float& cls);
 template <bool QUANT>
 __global__ __launch_bounds__(256) void crawl_table_k(SceneDev S, unsigned width, unsigned height, int control_draw, const unsigned char* danger, float4* table)
 {
@@ -774,7 +801,8 @@ __global__ __launch_bounds__(256) void crawl_table_k(SceneDev S, unsigned width,
     // certified-empty distance of the whole camera ray (see danger_k / certified_empty_distance below), then measured from
     // where the walk ends: the origins of the restart segments differ from o + d * (walked distance) by the rounding of a
     // few dozen additions (1e-5), against a safety margin of three quarters of a cell
-    float t_left = S.linear ? certified_empty_distance(S, ro, rd, danger) : 0.0f;
+    float cls = 0.0f;
+    float t_left = S.linear ? certified_empty_distance(S, ro, rd, danger, cls) : 0.0f;
     unsigned segs = 0, draws = 0;
     for (; segs < 700u; segs++)   // far below the bounded kernel's 800-segment cap, and both counts stay within 16 bits
     {
@@ -790,7 +818,7 @@ __global__ __launch_bounds__(256) void crawl_table_k(SceneDev S, unsigned width,
         t_left -= t_far;
     }
     table[2 * idx]     = make_float4(ro.x, ro.y, ro.z, u2f(segs | (draws << 16)));
-    table[2 * idx + 1] = make_float4(t_left > 0.0f ? t_left : 0.0f, 0.0f, 0.0f, 0.0f);
+    table[2 * idx + 1] = make_float4(t_left > 0.0f ? t_left : 0.0f, cls, 0.0f, 0.0f);
 }
 
 // ---- certified-empty distances of the camera rays (global-majorant estimator).
@@ -826,11 +854,15 @@ __global__ __launch_bounds__(256) void danger_k(SceneDev S, unsigned char* out)
             }
     out[idx] = any ? 1 : 0;
 }
-// distance from the origin up to which the ray (o, d) runs through certified-empty cells; 0 = no certificate
-__device__ float certified_empty_distance(const SceneDev& S, f3 ro, f3 rd, const unsigned char* danger)
+// distance from the origin up to which the ray (o, d) runs through certified-empty cells; 0 = no certificate.
+// cls: 0 general, 1 the certificate covers the whole chord (the path can never collide), 2 the ray misses the box (the
+// integrator's own test, intersectBox kernel.cu:654-680, says so: the path is the environment lookup alone)
+__device__ float certified_empty_distance(const SceneDev& S, f3 ro, f3 rd, const unsigned char* danger, float& cls)
 {
     float t_near, tf;
     bool  hit = intersect_box(ro, rd, S, t_near, tf);
+    cls = 0.0f;
+    if (!hit && danger) cls = 2.0f;
     if (!danger || !hit || !(tf == tf) || !(t_near == t_near)) return 0.0f;
     float t0 = fmaxf(t_near, 0.0f);
     // a quarter of the smallest cell edge, in world units (the direction is a unit vector)
@@ -854,6 +886,7 @@ __device__ float certified_empty_distance(const SceneDev& S, f3 ro, f3 rd, const
         }
         if (n == 199999u) t_empty = 0.0f;  // never on a sane scene: no certificate rather than a wrong one
     }
+    if (t_empty >= 1e29f) cls = 1.0f;
     return t_empty > t0 ? t_empty : 0.0f;
 }
 // per pixel two float4: [0] unused here (the local-majorant estimators keep the end of the restart crawl there), [1].x = the
@@ -865,29 +898,35 @@ __global__ __launch_bounds__(256) void empty_table_k(SceneDev S, unsigned width,
     unsigned py = idx / width, px = idx - py * width;
     f3 ro, rd;
     camera_ray(S, width, height, px, py, ro, rd);
+    float cls;
+    float te = certified_empty_distance(S, ro, rd, danger, cls);
     table[2 * idx]     = make_float4(ro.x, ro.y, ro.z, 0.0f);
-    table[2 * idx + 1] = make_float4(certified_empty_distance(S, ro, rd, danger), 0.0f, 0.0f, 0.0f);
+    table[2 * idx + 1] = make_float4(te, cls, 0.0f, 0.0f);
 }
 
 // per pixel, add the staged samples in frame order:  acc = (((acc + s0) + s1) + ...)
 __global__ __launch_bounds__(256) void reduce_stage_k(LaunchDev L)
 {
-    unsigned per_frame = L.ntiles_owned * 64u;
-    unsigned slot      = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= per_frame) return;
-    unsigned ot = slot >> 6, w = slot & 63u;
-    unsigned tx, ty;
-    owned_tile(ot, L.tiles_per_row, L.rank, L.world, tx, ty);
-    unsigned px = tx * 8u + (w & 7u), py = ty * 8u + (w >> 3);
-    if (px >= L.P.width || py >= L.P.height) return;
-    size_t idx = (size_t)px + (size_t)py * L.P.width;
-    float4 a   = L.out[idx];
+    // L.pixels / L.nslots: ALL pixels of the rank (every class); L.stage: the first of L.nframes staged frames
+    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= L.nslots) return;
+    unsigned pix = L.pixels[slot];
+    size_t   idx = (size_t)(pix & 0xffffu) + (size_t)(pix >> 16) * L.P.width;
+    float4   a   = L.out[idx];
     for (int f = 0; f < L.nframes; f++)
     {
-        float4 v = L.stage[(size_t)f * per_frame + slot];
+        float4 v = L.stage[(size_t)f * L.stage_stride + slot];
         a        = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
     }
     L.out[idx] = a;
+}
+
+// class of each pixel from the pixel table: 1 = light (its camera ray misses the box or meets certified-empty cells over its
+// whole chord), 0 = general
+__global__ void pixel_class_k(const float4* table, unsigned npixels, unsigned char* out)
+{
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npixels) out[i] = table[2 * (size_t)i + 1].y >= 1.0f ? 1 : 0;
 }
 
 // expand a dense volume into per-voxel 2x2x2 neighbourhood cells (clamped at the border)
@@ -1191,6 +1230,29 @@ static void launch_render_p7(const SceneDev& S, const LaunchDev& L, bool quant, 
     else launch_render5<EST, RngPhilox7, LDSB, false, false>(S, L, quant, count, blocks, st);
 }
 
+void launch_render_light(const SceneDev& S, const LaunchDev& L, int rng, bool count, int blocks, hipStream_t st)
+{
+    const ParamDev& P = L.P;
+    const bool ach = P.sigma_t[0] == P.sigma_t[1] && P.sigma_t[1] == P.sigma_t[2] && P.albedo[0] == P.albedo[1] && P.albedo[1] == P.albedo[2];
+    const dim3 g(blocks), b(VP_BLOCK);
+#define VP_LIGHT_LAUNCH(RNGT)                                                                                                          \
+    do                                                                                                                                 \
+    {                                                                                                                                  \
+        if (ach) { if (count) hipLaunchKernelGGL((render_k<EST_GLOBAL, RNGT, true, true, false, true, false, 0, true>), g, b, 0, st, S, L);   \
+                   else hipLaunchKernelGGL((render_k<EST_GLOBAL, RNGT, true, false, false, true, false, 0, true>), g, b, 0, st, S, L); }      \
+        else { if (count) hipLaunchKernelGGL((render_k<EST_GLOBAL, RNGT, true, true, false, false, false, 0, true>), g, b, 0, st, S, L);      \
+               else hipLaunchKernelGGL((render_k<EST_GLOBAL, RNGT, true, false, false, false, false, 0, true>), g, b, 0, st, S, L); }         \
+    } while (0)
+    if (rng == RNG_PHILOX) VP_LIGHT_LAUNCH(RngPhilox);
+    else if (rng == RNG_PHILOX7) VP_LIGHT_LAUNCH(RngPhilox7);
+    else VP_LIGHT_LAUNCH(RngSamplerH);
+#undef VP_LIGHT_LAUNCH
+}
+void launch_pixel_classes(const float4* table, unsigned npixels, unsigned char* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(pixel_class_k, dim3((npixels + 255) / 256), dim3(256), 0, st, table, npixels, out);
+}
+
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
                    int blocks, hipStream_t st)
 {
@@ -1340,7 +1402,7 @@ void launch_empty_table(const SceneDev& S, unsigned width, unsigned height, cons
 }
 void launch_reduce(const LaunchDev& L, hipStream_t st)
 {
-    unsigned per_frame = L.ntiles_owned * 64u;
+    unsigned per_frame = L.nslots;
     hipLaunchKernelGGL(reduce_stage_k, dim3((per_frame + 255) / 256), dim3(256), 0, st, L);
 }
 void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, hipStream_t st)

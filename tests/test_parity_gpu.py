@@ -89,6 +89,37 @@ def test_julia64_chromatic_bricks(vp, oracle, brick):
     buf.free()
 
 
+@pytest.mark.parametrize("rng_mode", [0, 1, 2])
+def test_global_majorant_chromatic_light_and_general_pixels(vp, oracle, rng_mode):
+    """Global-majorant estimator on a chromatic medium (the null-collision weights are not exactly 1, so the throughput of a
+    path depends on how many steps it took): pixels whose camera ray meets only empty cells run the light kernel, the others
+    the general one, side by side.  Image and work counters == oracle for the sequential sampler.h stream (whose unused
+    collision variate must still be consumed) and both counter-based ones; the pixel table holds all three classes."""
+    grid = oracle.julia(64)
+    osc, oP, vP = _setup(vp, oracle, grid, 0, rng_mode, brick=1, preset=scenes.PRESET1, key=(5, 77))
+    t = vp.pixel_table(vP)
+    classes = np.bincount(t[..., 5].astype(int).ravel(), minlength=3)
+    assert classes.min() > 50, classes                      # general, certified-empty and box-missing pixels all occur
+    ref, cnt = _oracle_frames(osc, oP, range(5))
+    buf = vp.DeviceBuffer(W, H)
+    vp.enable_counters(True)
+    vp.read_counters(reset=True)
+    vp.render_frames(buf.ptr, 0, 5, vP)
+    got = buf.download()
+    c = vp.read_counters()
+    vp.enable_counters(False)
+    assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+    for k in ("samples", "density_lookups", "env_lookups", "scatters"):
+        assert c[k] == cnt[k], (k, c[k], cnt[k])
+    assert 0 < c["density_loads"] < 0.6 * c["density_lookups"]     # most fetches are certified away
+    # frame by frame through the reference's entry point (direct accumulation, both kernels into one buffer)
+    buf.reset()
+    for f in range(5):
+        vp.render_kernel(buf.ptr, f, vP)
+    assert np.array_equal(buf.download(), ref)
+    buf.free()
+
+
 @pytest.mark.parametrize("quantized", [True, False])
 @pytest.mark.parametrize("linear", [True, False])
 def test_blob_volume_filter_modes(vp, oracle, quantized, linear):
