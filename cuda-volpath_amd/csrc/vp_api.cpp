@@ -87,7 +87,8 @@ struct State
     // where the restart crawl in front of the volume ends, per pixel (crawl_table_k); rebuilt when what it depends on changes
     bool        use_crawl_table = true;
     bool        use_empty_table = true;   // global-majorant estimator: certified-empty distances of the camera rays
-    bool        use_light   = true;       // ... and the light kernel for tiles whose rays all meet empty cells only
+    bool        use_light   = true;       // ... and the light kernel for pixels whose ray meets empty cells only
+    bool        use_light_local = true;   // ... also for the local-majorant estimators
     // the pixels this context owns (those of its tiles), class by class: [general..., light...], each y << 16 | x
     unsigned*   d_tiles     = nullptr;
     size_t      tiles_cap   = 0;
@@ -98,8 +99,9 @@ struct State
     bool        light_overlap = true;
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t  aux_ev[3][2]  = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-    // resident 256-thread workgroups per CU while both kernels run: 3 + 4 measured best on C2 (profiles/r02_light_overlap.txt)
-    unsigned    general_blocks_per_cu = 3, light_blocks_per_cu = 4;
+    // resident 256-thread workgroups per CU while both kernels run (0 = the measured defaults of profiles/r02_light_overlap.txt:
+    // 3 + 4 for the global-majorant estimator, 5 + 2 for the local-majorant ones)
+    unsigned    general_blocks_per_cu = 0, light_blocks_per_cu = 0;
     unsigned char* d_danger = nullptr;    // per cell: a non-empty cell within its 3x3x3 neighbourhood (danger_k)
     float4*     d_crawl     = nullptr;
     size_t      crawl_bytes = 0;
@@ -206,6 +208,7 @@ int ensure_device()
     if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;
     if (knob("VP_NO_LIGHT", 0, 1, v)) G.use_light = v == 0;
     if (knob("VP_NO_LIGHT_OVERLAP", 0, 1, v)) G.light_overlap = v == 0;
+    if (knob("VP_NO_LIGHT_LOCAL", 0, 1, v)) G.use_light_local = v == 0;
     if (knob("VP_GENERAL_BLOCKS_PER_CU", 1, 8, v)) G.general_blocks_per_cu = (unsigned)v;
     if (knob("VP_LIGHT_BLOCKS_PER_CU", 1, 8, v)) G.light_blocks_per_cu = (unsigned)v;
     if (knob("VP_LOOKAHEAD", 0, 4096, v)) G.la_max = (int)v;
@@ -522,7 +525,7 @@ int ensure_crawl_table(const Param* p, const float4** out)
 // pixel_class_k over the pixel table).  Rebuilt when the image size, the shard or the table changes.
 int ensure_pixel_lists(const Param* p, const float4* table, const Shard& sh)
 {
-    const bool light = G.use_light && table && G.est == VP_EST_GLOBAL && G.trk == VP_TRACK_SPECTRAL;
+    const bool light = G.use_light && table && G.trk == VP_TRACK_SPECTRAL && !(G.est != VP_EST_GLOBAL && !G.use_light_local);
     struct K { unsigned w, h, rank, world; int light; };
     std::vector<unsigned char> key(sizeof(K), 0);
     K* k = reinterpret_cast<K*>(key.data());
@@ -665,8 +668,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             unsigned blocks = (waves + (bsz / 64) - 1) / (bsz / 64);
             const bool     both = G.n_light && G.n_general;
             unsigned       bpc  = G.blocks_per_cu;
-            if (both && cls && G.light_blocks_per_cu) bpc = G.light_blocks_per_cu;
-            if (both && !cls && G.general_blocks_per_cu) bpc = G.general_blocks_per_cu;
+            if (both && cls) bpc = G.light_blocks_per_cu ? G.light_blocks_per_cu : (G.est == VP_EST_GLOBAL ? 4u : 2u);
+            if (both && !cls) bpc = G.general_blocks_per_cu ? G.general_blocks_per_cu : (G.est == VP_EST_GLOBAL ? 3u : 5u);
             unsigned cap    = (unsigned)G.num_cu * (ldsb ? 2u : bpc);
             if (blocks > cap) blocks = cap;
             if (cls)
@@ -681,7 +684,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                         if (!G.aux_ev[ti][q] && hipEventCreateWithFlags(&G.aux_ev[ti][q], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G.aux_ev[ti][q] = nullptr; }
                     if (G.aux_stream[ti] && G.aux_ev[ti][0] && G.aux_ev[ti][1] && e0 && hipStreamWaitEvent(G.aux_stream[ti], e0, 0) == hipSuccess) ls = G.aux_stream[ti];
                 }
-                launch_render_light(S, L, G.rng, G.count, (int)blocks, ls);
+                launch_render_light(S, L, G.est, G.rng, G.quant, G.count, (int)blocks, ls);
                 le = hipGetLastError();
                 if (ls != T.stream && le == hipSuccess)
                 {

@@ -74,8 +74,8 @@ struct LaunchDev
 
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
                    int blocks, hipStream_t st);
-// the light class of the global-majorant estimator (spectral tracking): tiles whose camera rays meet empty cells only
-void launch_render_light(const SceneDev& S, const LaunchDev& L, int rng, bool count, int blocks, hipStream_t st);
+// the light pixel class (spectral tracking): pixels whose camera ray meets empty cells only
+void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int blocks, hipStream_t st);
 void launch_pixel_classes(const float4* table, unsigned npixels, unsigned char* out, hipStream_t st);
 void launch_env_tables(const float4* env, int w, int h, float* lum, float* row_sum, float* cdf_x, float* cdf_y, float* pdfnorm_alt,
                        hipStream_t st);

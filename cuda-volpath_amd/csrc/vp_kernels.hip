@@ -52,9 +52,10 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
 // build, kernel.cu:2220-2297); the shipped configuration is passive (MIS = false).
 // TRK: 0 = spectral tracking (SPECTRAL_TRACKING 1, the shipped build); 1 = scalar tracking (SPECTRAL_TRACKING 0);
 // 2 = MULTI_CHANNEL 1: scalar tracking of one colour channel drawn per sample (kernel.cu:15-34, :1993-1994, :2311-2313).
-// LIGHT: the kernel of the "light" pixel class (global-majorant estimator, spectral tracking): every camera ray of those pixels
-// either misses the box or meets certified-empty cells over its whole chord (empty_table_k), so a path is: free-flight steps
-// whose null collisions have den = +0 folded in, then the environment.  No fetch code, no collision, shadow or phase states.
+// LIGHT: the kernel of the "light" pixel class (spectral tracking): every camera ray of those pixels either misses the box or
+// meets certified-empty cells over its whole chord (empty_table_k / crawl_table_k), so a path is: restart segments (local-majorant
+// estimators) and free-flight steps whose null collisions have den = +0, then the environment.  No fetch code, no collision,
+// shadow or phase states.
 template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool MIS, int TRK, bool LIGHT = false>
 // The local-majorant kernels need 98 VGPRs when left alone, two more than five waves per SIMD allow (512 / 5 -> 96):
 // asking for five costs no spill and is +10 % on the reference-table decomposition workload.  The global-majorant
@@ -555,7 +556,7 @@ void render_k(SceneDev S, LaunchDev L)
         };
         auto tracking_step = [&]() __attribute__((always_inline)) {
             tally(B_HALF, st == ST_TRACK || st == ST_SHADOW);
-            if (LIGHT)
+            if (LIGHT && !LOCAL)
             {
                 // Every fetch of this path would filter eight zero texels (certified: the whole chord): the general expressions
                 // below with den = +0 reduce exactly to sigma_t_den = +0, Ps = +0, c = Pn, `real` false for any draw and
@@ -616,7 +617,7 @@ void render_k(SceneDev S, LaunchDev L)
                         {
                             if (MIS) seg_o = ro;
                             ro = ro + rd * distc;  // control collision kernel.cu:2088
-                            st = EV_SCATTER;
+                            st = LIGHT ? EV_WRITE : EV_SCATTER;  // (LIGHT: excluded by the pixel class, which checks the brick minima)
                         }
                     }
                     else
@@ -626,8 +627,9 @@ void render_k(SceneDev S, LaunchDev L)
                 {
                     f3    p   = ro + rd * dist;
                     float den;
-                    tally(B_FETCH, shadow || !(dist < t_empty));
-                    if (EST == EST_GLOBAL)
+                    tally(B_FETCH, !LIGHT && (shadow || !(dist < t_empty)));
+                    if (LIGHT) den = 0.0f;  // light class of a local-majorant estimator: every fetch is certified to return +0
+                    else if (EST == EST_GLOBAL)
                     {
                         // Before t_empty every texel this fetch would filter is zero (empty_table_k): the product is +0 without
                         // position, address, load or filter.  Whole waves of background rays take this branch together.
@@ -689,7 +691,7 @@ void render_k(SceneDev S, LaunchDev L)
                         {
                             if (MIS) seg_o = ro;
                             ro = p;
-                            st = EV_SCATTER;
+                            st = LIGHT ? EV_WRITE : EV_SCATTER;  // (LIGHT: den = +0 makes `real` false)
                         }
                     }
                     else
@@ -717,7 +719,7 @@ void render_k(SceneDev S, LaunchDev L)
                         {
                             if (MIS) seg_o = ro;
                             ro = p;
-                            st = EV_SCATTER;
+                            st = LIGHT ? EV_WRITE : EV_SCATTER;  // (LIGHT: den = +0 makes `real` false)
                         }
                     }
                 }
@@ -790,6 +792,8 @@ void render_k(SceneDev S, LaunchDev L)
 // kernel.cu:2048-2054).  A path then starts at the first segment that can interact.  Bit-identical by construction.
 __device__ float certified_empty_distance(const SceneDev& S, f3 ro, f3 rd, const unsigned char* danger, float& cls);
 template <bool QUANT>
+__device__ bool chord_has_positive_minimum(const SceneDev& S, f3 ro, f3 rd);
+template <bool QUANT>
 __global__ __launch_bounds__(256) void crawl_table_k(SceneDev S, unsigned width, unsigned height, int control_draw, const unsigned char* danger, float4* table)
 {
     unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -803,6 +807,7 @@ __global__ __launch_bounds__(256) void crawl_table_k(SceneDev S, unsigned width,
     // few dozen additions (1e-5), against a safety margin of three quarters of a cell
     float cls = 0.0f;
     float t_left = S.linear ? certified_empty_distance(S, ro, rd, danger, cls) : 0.0f;
+    if (cls == 1.0f && chord_has_positive_minimum<QUANT>(S, ro, rd)) cls = 0.0f;
     unsigned segs = 0, draws = 0;
     for (; segs < 700u; segs++)   // far below the bounded kernel's 800-segment cap, and both counts stay within 16 bits
     {
@@ -857,6 +862,27 @@ __global__ __launch_bounds__(256) void danger_k(SceneDev S, unsigned char* out)
 // distance from the origin up to which the ray (o, d) runs through certified-empty cells; 0 = no certificate.
 // cls: 0 general, 1 the certificate covers the whole chord (the path can never collide), 2 the ray misses the box (the
 // integrator's own test, intersectBox kernel.cu:654-680, says so: the path is the environment lookup alone)
+template <bool QUANT>
+__device__ bool chord_has_positive_minimum(const SceneDev& S, f3 ro, f3 rd)
+{
+    // a restart segment whose brick has a positive minimum draws a control distance (decomposition estimator) and may end in a
+    // control collision; a light pixel must have none on its chord.  (A ray through empty cells cannot meet one -- the voxel
+    // under a segment start is a texel of the cell there -- this march makes it a checked property, in steps of a quarter cell.)
+    float t_near, tf;
+    if (!intersect_box(ro, rd, S, t_near, tf)) return false;
+    float t0   = fmaxf(t_near, 0.0f);
+    float cell = fminf(fminf((S.bmax[0] - S.bmin[0]) / (float)S.nx, (S.bmax[1] - S.bmin[1]) / (float)S.ny), (S.bmax[2] - S.bmin[2]) / (float)S.nz);
+    float ds   = 0.25f * cell;
+    for (unsigned n = 0; n < 200000u; n++)
+    {
+        float tt = t0 + (float)n * ds;
+        if (tt > tf + ds) return false;
+        float bx, by;
+        sample_bound<QUANT>(S, ro + rd * tt, bx, by);
+        if (by > 0.0f) return true;
+    }
+    return true;
+}
 __device__ float certified_empty_distance(const SceneDev& S, f3 ro, f3 rd, const unsigned char* danger, float& cls)
 {
     float t_near, tf;
@@ -1230,23 +1256,52 @@ static void launch_render_p7(const SceneDev& S, const LaunchDev& L, bool quant, 
     else launch_render5<EST, RngPhilox7, LDSB, false, false>(S, L, quant, count, blocks, st);
 }
 
-void launch_render_light(const SceneDev& S, const LaunchDev& L, int rng, bool count, int blocks, hipStream_t st)
+template <int EST, class RNGT>
+static void launch_light2(const SceneDev& S, const LaunchDev& L, bool quant, bool count, bool ach, int blocks, hipStream_t st)
+{
+    const dim3 g(blocks), b(VP_BLOCK);
+    // QUANT only selects how the bound table of the local-majorant estimators is read; the light kernels fetch no cells
+    constexpr bool LOC = EST != EST_GLOBAL;
+#define VP_LL(Q, C, A) hipLaunchKernelGGL((render_k<EST, RNGT, Q, C, false, A, false, 0, true>), g, b, 0, st, S, L)
+    if (LOC && !quant)
+    {
+        if (ach) { if (count) VP_LL(false, true, true); else VP_LL(false, false, true); }
+        else { if (count) VP_LL(false, true, false); else VP_LL(false, false, false); }
+    }
+    else
+    {
+        if (ach) { if (count) VP_LL(true, true, true); else VP_LL(true, false, true); }
+        else { if (count) VP_LL(true, true, false); else VP_LL(true, false, false); }
+    }
+#undef VP_LL
+}
+void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int blocks, hipStream_t st)
 {
     const ParamDev& P = L.P;
     const bool ach = P.sigma_t[0] == P.sigma_t[1] && P.sigma_t[1] == P.sigma_t[2] && P.albedo[0] == P.albedo[1] && P.albedo[1] == P.albedo[2];
-    const dim3 g(blocks), b(VP_BLOCK);
-#define VP_LIGHT_LAUNCH(RNGT)                                                                                                          \
-    do                                                                                                                                 \
-    {                                                                                                                                  \
-        if (ach) { if (count) hipLaunchKernelGGL((render_k<EST_GLOBAL, RNGT, true, true, false, true, false, 0, true>), g, b, 0, st, S, L);   \
-                   else hipLaunchKernelGGL((render_k<EST_GLOBAL, RNGT, true, false, false, true, false, 0, true>), g, b, 0, st, S, L); }      \
-        else { if (count) hipLaunchKernelGGL((render_k<EST_GLOBAL, RNGT, true, true, false, false, false, 0, true>), g, b, 0, st, S, L);      \
-               else hipLaunchKernelGGL((render_k<EST_GLOBAL, RNGT, true, false, false, false, false, 0, true>), g, b, 0, st, S, L); }         \
+#ifdef VP_DEV_BUILD
+    if (rng == RNG_SAMPLERH || est == EST_BOUNDED) { fprintf(stderr, "volpath_hip DEV build: this kernel variant is not compiled\n"); abort(); }
+#define VP_LE(RNGT)                                                                             \
+    do                                                                                          \
+    {                                                                                           \
+        if (est == EST_DECOMP) launch_light2<EST_DECOMP, RNGT>(S, L, true, count, ach, blocks, st);  \
+        else launch_light2<EST_GLOBAL, RNGT>(S, L, true, count, ach, blocks, st);                    \
     } while (0)
-    if (rng == RNG_PHILOX) VP_LIGHT_LAUNCH(RngPhilox);
-    else if (rng == RNG_PHILOX7) VP_LIGHT_LAUNCH(RngPhilox7);
-    else VP_LIGHT_LAUNCH(RngSamplerH);
-#undef VP_LIGHT_LAUNCH
+    if (rng == RNG_PHILOX) VP_LE(RngPhilox);
+    else VP_LE(RngPhilox7);
+#else
+#define VP_LE(RNGT)                                                                             \
+    do                                                                                          \
+    {                                                                                           \
+        if (est == EST_DECOMP) launch_light2<EST_DECOMP, RNGT>(S, L, quant, count, ach, blocks, st);        \
+        else if (est == EST_BOUNDED) launch_light2<EST_BOUNDED, RNGT>(S, L, quant, count, ach, blocks, st); \
+        else launch_light2<EST_GLOBAL, RNGT>(S, L, quant, count, ach, blocks, st);                          \
+    } while (0)
+    if (rng == RNG_PHILOX) VP_LE(RngPhilox);
+    else if (rng == RNG_PHILOX7) VP_LE(RngPhilox7);
+    else VP_LE(RngSamplerH);
+#endif
+#undef VP_LE
 }
 void launch_pixel_classes(const float4* table, unsigned npixels, unsigned char* out, hipStream_t st)
 {
