@@ -29,11 +29,14 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
 REFERENCE_ESTIMATOR_BYTES_PER_SAMPLE = 8 * 97.6 + 2 * 51.3 + 16 * 1.0 + 32
 
 
-def algorithmic_bytes_per_sample(c):
-    """8*L_d + 2*L_b + 32*L_o + 16*L_e + 32 (accumulator read+write)."""
+def algorithmic_bytes_per_sample(c, loads=False):
+    """8*L_d + 2*L_b + 32*L_o + 16*L_e + 32 (accumulator read+write).
+    L_d = trilinear density lookups the estimator asks for (the oracle counts the same number); with loads=True the lookups
+    that really issued a load: free-flight steps of a camera ray through certified-empty cells use the +0 such a fetch
+    returns without fetching."""
     n = max(c["samples"], 1)
-    return (8.0 * c["density_lookups"] + 2.0 * c["bound_lookups"] + 32.0 * c["opacity_lookups"] +
-            16.0 * c["env_lookups"]) / n + 32.0
+    ld = c["density_loads"] if loads else c["density_lookups"]
+    return (8.0 * ld + 2.0 * c["bound_lookups"] + 32.0 * c["opacity_lookups"] + 16.0 * c["env_lookups"]) / n + 32.0
 
 
 def effective_cores():
@@ -59,7 +62,7 @@ def cpu_baseline(workload, seconds_hint=20.0):
     grid = O.julia(cfg["n"])
     env, sun_dir, sun_power = vscene.default_sunsky()
     osc = O.OracleScene(grid, env, sun_dir, sun_power,
-                        brick=cfg["brick"], estimator=cfg["est"], rng_mode=O.RNG_PHILOX, seed=(0x9E3779B9, 0x85EBCA6B))
+                        brick=cfg["brick"], estimator=cfg["est"], rng_mode=O.RNG_PHILOX7, seed=(0x9E3779B9, 0x85EBCA6B))
     P = O.default_param(cfg["width"], cfg["height"])
     if cfg["chromatic"]:
         O.mat(P, *vscene.PRESET1)
@@ -82,7 +85,7 @@ def cpu_baseline(workload, seconds_hint=20.0):
     dt = time.time() - t0
     return {"value": tot / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"frames 0..{nframes - 1} of {cfg['width']}x{cfg['height']} ({tot} samples, {dt:.1f} s, "
-                      f"OpenMP over rows, Philox streams"
+                      f"OpenMP over rows, Philox2x32-7 streams"
                       + ("; frames 11+ would read the optical-depth table, whose CPU precompute is not affordable here)"
                          if cfg["est"] == O.EST_DECOMP and not across_q5 else ")")}
 
@@ -94,7 +97,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3ref", "c1", "c4s"])
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
-    ap.add_argument("--rng", default="philox", choices=["philox", "samplerh"])
+    ap.add_argument("--rng", default="philox7", choices=["philox", "philox7", "samplerh"],
+                    help="philox7 = Philox2x32-7 (default: the fewest rounds Random123 documents as Crush-resistant; oracle parity "
+                         "like the others), philox = Philox2x32-10 (the round-1 default, 4-6 %% slower), samplerh = the reference's "
+                         "sampler.h streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-image", default=None, help="rank 0 saves the summed HDR image (.npy) -- used by tests")
     args = ap.parse_args()
@@ -130,7 +136,7 @@ def main():
 
     spp_step = args.spp * world
     total_steps = args.warmup + args.steps
-    rng_mode = vp.RNG_PHILOX if args.rng == "philox" else vp.RNG_SAMPLERH
+    rng_mode = {"philox": vp.RNG_PHILOX, "philox7": vp.RNG_PHILOX7, "samplerh": vp.RNG_SAMPLERH}[args.rng]
     count_frames = 4 if args.workload == "c2" else 16  # frames of the (untimed) work-counter pass
     P, info = vscene.setup(args.workload, rng_mode=rng_mode, rank=rank, world=world,
                            last_frame=max(spp_step * total_steps, count_frames))
@@ -152,6 +158,7 @@ def main():
         counters = vp.read_counters(reset=True)
         vp.enable_counters(False)
         bytes_per_sample = algorithmic_bytes_per_sample(counters)
+        fetched_bytes_per_sample = algorithmic_bytes_per_sample(counters, loads=True)
 
         def step(i):
             acc.zero_()
@@ -217,7 +224,8 @@ def main():
             "config": {"workload": info["name"], "volume": f"{info['n']}^3 uchar Julia set", "image": f"{W}x{H}",
                        "spp_per_step": spp_step, "samples_per_step": int(W * H * spp_step),
                        "estimator": "global_majorant" if info["est"] == vp.EST_GLOBAL else "decomposition",
-                       "bound_brick": info["brick"], "rng": args.rng,
+                       "bound_brick": info["brick"],
+                       "rng": {"philox": "philox2x32-10", "philox7": "philox2x32-7", "samplerh": "sampler.h"}[args.rng],
                        "parallelism": f"pixel-tiles x{world}" + (" + RCCL reduce" if world > 1 else ""),
                        "sky": "Hosek sun/sky bake, setup_sunsky(0.5, 0.2), 1024x512"},
             # bound/achieved/peak/frac: the contract's HBM roofline on ALGORITHMIC bytes.  What really bounds this kernel is
@@ -228,11 +236,16 @@ def main():
                          "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic else None,
                          "bounded_by": "valu_issue", "valu_issue_frac": valu_frac, "valu_issue_peak_per_s": VALU_ISSUE_PEAK,
                          "lane_util": lane_util,
-                         "kernel": "vp::render_k", "launch_ms": launch_ms, "launches": launches,
+                         "kernel": "vp::render_k (a launch = the general kernel and, beside it on a second stream, the light kernel "
+                                   "of the pixels whose camera ray meets empty cells only; HIP events from the start of the "
+                                   "first to the end of the last)",
+                         "launch_ms": launch_ms, "launches": launches,
                          "algorithmic_bytes_per_sample": bytes_per_sample,
+                         "fetched_bytes_per_sample": fetched_bytes_per_sample,
+                         "fetched_GBps": fetched_bytes_per_sample * samples_rank / launches / (launch_ms * 1e-3) / 1e9,
                          "reference_estimator_bytes_per_sample": REFERENCE_ESTIMATOR_BYTES_PER_SAMPLE,
                          "lookups_per_sample": {k: counters[k] / max(counters["samples"], 1) for k in
-                                                ("density_lookups", "bound_lookups", "opacity_lookups", "env_lookups", "scatters")}},
+                                                ("density_lookups", "density_loads", "bound_lookups", "opacity_lookups", "env_lookups", "scatters")}},
         }
         if world > 1:
             mean_k = sum(kerns) / world

@@ -1,21 +1,42 @@
-"""Digest of scripts/profile_bench.sh output: per-launch averages of the render kernel."""
+"""Digest of scripts/profile_bench.sh output: per-launch averages of the render launch.
+
+A render launch is the general kernel render_k<..., LIGHT=false> and, where the workload has light pixels, the light kernel
+render_k<..., LIGHT=true> beside it on a second stream; bench.py times the pair with HIP events from the start of the first
+to the end of the last.  Counters are summed over both kernels of the timed (non-counting) variant and divided by the number
+of launches (= dispatches of the general kernel)."""
 import collections, csv, glob, json, re, sys
 out = sys.argv[1]
 res = {}
+
+
+def variant(name):
+    name = re.sub(r"RngPhiloxR<\d+>", "RngPhiloxR", name)
+    m = re.search(r"render_k<([^>]*)>", name)
+    if not m:
+        return None
+    a = [x.strip() for x in m.group(1).split(",")]
+    return {"count": a[3] == "true", "light": len(a) > 8 and a[8] == "true"}
+
+
 ks = glob.glob(f"{out}/kt/**/*kernel_stats.csv", recursive=True)
 if ks:
-    rows = [r for r in csv.DictReader(open(ks[0])) if "render_k" in r["Name"]]
-    r = max(rows, key=lambda r: int(r["Calls"]))  # the timed (non-counting) variant
-    res["kernel_trace"] = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
-                           "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"])}
+    rows = [(r, variant(r["Name"])) for r in csv.DictReader(open(ks[0])) if "render_k" in r["Name"]]
+    rows = [(r, v) for r, v in rows if v and not v["count"]]
+    for key, light in (("kernel_trace", False), ("kernel_trace_light", True)):
+        sel = [r for r, v in rows if v["light"] == light]
+        if sel:
+            r = max(sel, key=lambda r: float(r["TotalDurationNs"]))
+            res[key] = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                        "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"])}
 for d in ("fetch", "write", "sq", "tcc"):
     for f in glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(float); disp = set()
         for r in csv.DictReader(open(f)):
-            # the timed variant only: template args <EST, RNG, QUANT, COUNT=false>
-            m = re.search(r"render_k<([^>]*)>", r["Kernel_Name"])
-            if m and m.group(1).split(",")[3].strip() == "false":
-                agg[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
+            v = variant(r["Kernel_Name"])
+            if v and not v["count"]:
+                agg[r["Counter_Name"]] += float(r["Counter_Value"])
+                if not v["light"]:
+                    disp.add(r["Dispatch_Id"])
         n = max(len(disp), 1)
         res[d] = {"launches": len(disp), "per_launch": {k: v / n for k, v in agg.items()}}
 for d in ("kt", "fetch"):
