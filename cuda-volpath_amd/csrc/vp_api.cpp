@@ -92,7 +92,7 @@ struct State
     // the pixels this context owns (those of its tiles), class by class: [general..., light...], each y << 16 | x
     unsigned*   d_tiles     = nullptr;
     size_t      tiles_cap   = 0;
-    unsigned    n_general   = 0, n_light = 0;
+    unsigned    n_general   = 0, n_light = 0, n_miss = 0;
     std::vector<unsigned char> tiles_key;
     // the light kernel runs beside the general one on a stream of its own (ALU-bound waves fill the issue slots the general
     // kernel's waves leave while they wait for cells): one auxiliary stream and two events per launch target
@@ -520,9 +520,9 @@ int ensure_crawl_table(const Param* p, const float4** out)
 }
 
 // The pixel lists of this context: the pixels of its tiles, tile by tile (row-major tiles, row-major pixels within a tile: the
-// order keeps the rays of a wave in one pencil of the volume), general pixels first, then the light class (global-majorant
-// estimator with spectral tracking: camera rays that miss the box or meet certified-empty cells over their whole chord --
-// pixel_class_k over the pixel table).  Rebuilt when the image size, the shard or the table changes.
+// order keeps the rays of a wave in one pencil of the volume), general pixels first, then -- with spectral tracking and a pixel
+// table -- the light class (camera rays that meet certified-empty cells over their whole chord) and the pixels whose camera ray
+// misses the box (pixel_class_k over the pixel table).  Rebuilt when the image size, the shard or the table changes.
 int ensure_pixel_lists(const Param* p, const float4* table, const Shard& sh)
 {
     const bool light = G.use_light && table && G.trk == VP_TRACK_SPECTRAL && !(G.est != VP_EST_GLOBAL && !G.use_light_local);
@@ -547,15 +547,19 @@ int ensure_pixel_lists(const Param* p, const float4* table, const Shard& sh)
         (void)hipFree(d_cls);
         if (e != hipSuccess) return fail(VP_E_NODEVICE, "pixel classes -> %s", hipGetErrorString(e));
     }
-    std::vector<unsigned> general, lightv;
+    std::vector<unsigned> general, lightv, missv;
     general.reserve(sh.per_frame);
     for (unsigned ty = 0; ty < sh.tiles_y; ty++)
         for (unsigned tx = (G.rank + G.world - tile_row_shift(ty, G.world)) % G.world; tx < sh.tiles_x; tx += G.world)
             for (unsigned y = ty * 8u; y < ty * 8u + 8u && y < p->height; y++)
                 for (unsigned x = tx * 8u; x < tx * 8u + 8u && x < p->width; x++)
-                    (cls[(size_t)y * p->width + x] ? lightv : general).push_back(y << 16 | x);
-    G.n_general = (unsigned)general.size(); G.n_light = (unsigned)lightv.size();
+                {
+                    const unsigned char c = cls[(size_t)y * p->width + x];
+                    (c == 2 ? missv : c == 1 ? lightv : general).push_back(y << 16 | x);
+                }
+    G.n_general = (unsigned)general.size(); G.n_light = (unsigned)lightv.size(); G.n_miss = (unsigned)missv.size();
     general.insert(general.end(), lightv.begin(), lightv.end());
+    general.insert(general.end(), missv.begin(), missv.end());
     if (general.size() > G.tiles_cap)
     {
         if (G.d_tiles) HIPCHK(hipFree(G.d_tiles));
@@ -698,6 +702,16 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                 launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, G.trk, (int)blocks, T.stream);
                 le = hipGetLastError();
             }
+        }
+        if (G.n_miss && le == hipSuccess)
+        {
+            // the pixels whose camera ray misses the box: one constant per pixel, written for every frame (miss_fill_k)
+            L.pixels      = G.d_tiles + G.n_general + G.n_light;
+            L.nslots      = G.n_miss;
+            L.slot_base   = G.n_general + G.n_light;
+            L.total_items = 0;
+            launch_miss_fill(S, L, G.est != VP_EST_GLOBAL, T.stream);
+            le = hipGetLastError();
         }
         timed = timed && le == hipSuccess && hipEventRecord(e1, T.stream) == hipSuccess;
         G.timed_n++;

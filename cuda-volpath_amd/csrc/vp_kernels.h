@@ -76,6 +76,7 @@ void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool
                    int blocks, hipStream_t st);
 // the light pixel class (spectral tracking): pixels whose camera ray meets empty cells only
 void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int blocks, hipStream_t st);
+void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimator, hipStream_t st);
 void launch_pixel_classes(const float4* table, unsigned npixels, unsigned char* out, hipStream_t st);
 void launch_env_tables(const float4* env, int w, int h, float* lum, float* row_sum, float* cdf_x, float* cdf_y, float* pdfnorm_alt,
                        hipStream_t st);

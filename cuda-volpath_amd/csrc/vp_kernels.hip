@@ -857,7 +857,19 @@ __global__ __launch_bounds__(256) void danger_k(SceneDev S, unsigned char* out)
                     any = any || lo.x != 0.0f || lo.y != 0.0f || lo.z != 0.0f || lo.w != 0.0f || hi.x != 0.0f || hi.y != 0.0f || hi.z != 0.0f || hi.w != 0.0f;
                 }
             }
-    out[idx] = any ? 1 : 0;
+    // bit 0: a non-empty cell in the 3x3x3 neighbourhood; bit 1: this cell itself is non-empty
+    bool self;
+    {
+        size_t o = idx;
+        if (QUANT) { uint2 v = S.cells_u8[o]; self = (v.x | v.y) != 0u; }
+        else
+        {
+            const float4* q = reinterpret_cast<const float4*>(S.cells_f32) + o * 2;
+            float4 lo = q[0], hi = q[1];
+            self = lo.x != 0.0f || lo.y != 0.0f || lo.z != 0.0f || lo.w != 0.0f || hi.x != 0.0f || hi.y != 0.0f || hi.z != 0.0f || hi.w != 0.0f;
+        }
+    }
+    out[idx] = (unsigned char)((any ? 1 : 0) | (self ? 2 : 0));
 }
 // distance from the origin up to which the ray (o, d) runs through certified-empty cells; 0 = no certificate.
 // cls: 0 general, 1 the certificate covers the whole chord (the path can never collide), 2 the ray misses the box (the
@@ -905,10 +917,25 @@ __device__ float certified_empty_distance(const SceneDev& S, f3 ro, f3 rd, const
         axis_linear(p.x, S.nx, i, w);
         axis_linear(p.y, S.ny, j, w);
         axis_linear(p.z, S.nz, k, w);
-        if (danger[(size_t)i + (size_t)S.nx * ((size_t)j + (size_t)S.ny * k)])
+        if (danger[(size_t)i + (size_t)S.nx * ((size_t)j + (size_t)S.ny * k)] & 1)
         {
-            t_empty = fmaxf(tt - 2.0f * ds, 0.0f);
-            break;
+            // close to the medium: look at the cells themselves.  Every point of the ray within a quarter cell of this sample
+            // lies in a cell whose index is floor(c - 0.27) or floor(c + 0.27) per axis (c = continuous cell coordinate of the
+            // sample; 0.02 of a cell covers the rounding of positions, which is below 1e-4 of a cell): at most 2 x 2 x 2 cells.
+            bool hit_cell = false;
+            const float cx = fmaxf(fma_(p.x, (float)S.nx, -0.5f), 0.0f), cy = fmaxf(fma_(p.y, (float)S.ny, -0.5f), 0.0f),
+                        cz = fmaxf(fma_(p.z, (float)S.nz, -0.5f), 0.0f);
+            const int i0 = max((int)__builtin_floorf(cx - 0.27f), 0), i1 = min((int)__builtin_floorf(cx + 0.27f), S.nx - 1);
+            const int j0 = max((int)__builtin_floorf(cy - 0.27f), 0), j1 = min((int)__builtin_floorf(cy + 0.27f), S.ny - 1);
+            const int k0 = max((int)__builtin_floorf(cz - 0.27f), 0), k1 = min((int)__builtin_floorf(cz + 0.27f), S.nz - 1);
+            for (int c = k0; c <= k1; c++)
+                for (int b = j0; b <= j1; b++)
+                    for (int a = i0; a <= i1; a++) hit_cell = hit_cell || (danger[(size_t)a + (size_t)S.nx * ((size_t)b + (size_t)S.ny * c)] & 2);
+            if (hit_cell)
+            {
+                t_empty = fmaxf(tt - 2.0f * ds, 0.0f);
+                break;
+            }
         }
         if (n == 199999u) t_empty = 0.0f;  // never on a sane scene: no certificate rather than a wrong one
     }
@@ -952,7 +979,45 @@ __global__ __launch_bounds__(256) void reduce_stage_k(LaunchDev L)
 __global__ void pixel_class_k(const float4* table, unsigned npixels, unsigned char* out)
 {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npixels) out[i] = table[2 * (size_t)i + 1].y >= 1.0f ? 1 : 0;
+    if (i < npixels) out[i] = (unsigned char)table[2 * (size_t)i + 1].y;  // 0 general, 1 certified-empty chord, 2 misses the box
+}
+
+// The samples of a pixel whose camera ray misses the box are the same in every frame: set-up finds no hit (intersectBox,
+// kernel.cu:1336-1345 / :2020-2031), background() is evaluated for the camera direction with throughput 1 (quirk Q3: no jitter)
+// and the sample is written -- no draw is consumed.  One thread per such pixel evaluates that once, with the integrator's own
+// expressions (EV_BG / EV_WRITE blocks of render_k), and writes it for every frame of the launch.
+__global__ __launch_bounds__(256) void miss_fill_k(SceneDev S, LaunchDev L, int local_estimator)
+{
+    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= L.nslots) return;
+    const ParamDev& P = L.P;
+    unsigned pix = L.pixels[slot], px = pix & 0xffffu, py = pix >> 16;
+    f3 ro, rd;
+    camera_ray(S, P.width, P.height, px, py, ro, rd);
+    const f3 sun_dir = f3{S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]};
+    f3   rad  = f3{0.0f, 0.0f, 0.0f};
+    const f3 thr = f3{1.0f, 1.0f, 1.0f};
+    bool env_lookup = false;
+    f3   bg;
+    if (dot(rd, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
+    else { bg = eval_envmap(S, rd); env_lookup = true; }
+    rad = rad + bg * thr;
+    f3     r = rad * P.brightness;
+    float4 v = make_float4(fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f), fmaxf(r.z, 0.0f), 0.0f);  // heat: 0 scatters / segments
+    if (L.stage)
+        for (int f = 0; f < L.nframes; f++) L.stage[(size_t)f * L.stage_stride + L.slot_base + slot] = v;
+    else
+    {
+        size_t idx = (size_t)px + (size_t)py * P.width;
+        float4 a   = L.out[idx];
+        L.out[idx] = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
+    }
+    if (L.counters)
+    {
+        atomicAdd(&L.counters[0], (unsigned long long)L.nframes);                         // samples
+        if (env_lookup) atomicAdd(&L.counters[4], (unsigned long long)L.nframes);         // environment lookups
+        if (local_estimator) atomicAdd(&L.counters[2], (unsigned long long)L.nframes);    // the bound fetched before the hit test
+    }
 }
 
 // expand a dense volume into per-voxel 2x2x2 neighbourhood cells (clamped at the border)
@@ -1302,6 +1367,10 @@ void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng
     else VP_LE(RngSamplerH);
 #endif
 #undef VP_LE
+}
+void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimator, hipStream_t st)
+{
+    hipLaunchKernelGGL(miss_fill_k, dim3((L.nslots + 255) / 256), dim3(256), 0, st, S, L, local_estimator ? 1 : 0);
 }
 void launch_pixel_classes(const float4* table, unsigned npixels, unsigned char* out, hipStream_t st)
 {

@@ -153,8 +153,9 @@ def test_dense_dump_roundtrip_and_quantisers(host, tmp_path):
 
 
 def test_bench_cpu_baseline_leg_runs_for_every_estimator(host):
-    """bench.py's cpu_baseline (the oracle timed on the host) must work for the decomposition workloads too: their
-    sample stays within frames 0..10, before the live kernel starts reading the optical-depth volume (quirk Q5)."""
+    """bench.py's cpu_baseline (the oracle timed on the host) must work for the decomposition workloads too.  At 128^3 the
+    optical-depth volume is affordable on the CPU, so the sample runs across the frame-11 switch of the live kernel (quirk
+    Q5); at 256^3 and above it stays within frames 0..10 and says so."""
     import importlib.util
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -162,5 +163,5 @@ def test_bench_cpu_baseline_leg_runs_for_every_estimator(host):
     spec = importlib.util.spec_from_file_location("vp_bench", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    r = bench.cpu_baseline("c1", seconds_hint=60.0)      # Julia 128^3, 400x300, decomposition: 11 frames
-    assert r["kind"] == "port" and r["value"] > 0 and "frames 0..10" in r["sample"]
+    r = bench.cpu_baseline("c1", seconds_hint=60.0)      # Julia 128^3, 400x300, decomposition: 16 frames incl. 11..15
+    assert r["kind"] == "port" and r["value"] > 0 and "frames 0..15" in r["sample"] and "not affordable" not in r["sample"]
