@@ -381,3 +381,76 @@ def test_scatter_statistics_of_the_live_kernel_at_full_size(vp):
     assert abs(heat.max() / 205.0 - 1) < 0.15, heat.max()      # a maximum over 480 000 pixels: noisy, still within 15 %
     assert heat.mean() > 1.74                     # consistent with the percentiles, not with "1.58"
     assert abs(heat.mean() - 3.15) < 0.1
+
+
+# ------------------------------------------------------------------------------------------ the per-pixel certificates
+@pytest.mark.parametrize("est", [0, 1])
+def test_pixel_table_certificates_hold_in_float64(vp, est):
+    """The tables that let paths skip work are claims about geometry; checked here in float64 against
+    the raw volume, without the oracle: (a) before the certified-empty distance every point of the camera ray lies in a cell
+    whose 2x2x2 texels are all zero; (b) class 2 = the ray misses the box, class 1 = the whole chord is empty; (c) for the
+    local-majorant estimators the recorded origin is the camera origin moved by `segments` steps of 0.05 along the ray, all
+    of them in front of the box, and no draw beyond one per segment (the Julia grid has no brick with a positive minimum)."""
+    import scenes
+    rng = np.random.default_rng(8)
+    n = 48
+    grid = vp.julia_volume(n)
+    vp.init_volume(grid, brick=4 if est else 1, linear=True)
+    vp.init_envmap(scenes.synthetic_env())
+    vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+    vp.set_camera()
+    vp.set_estimator(est)
+    vp.set_tracking(0)
+    vp.set_shard(0, 1)
+    W, H = 160, 120
+    P = vp.make_param(W, H)
+    t = vp.pixel_table(P)
+    o, d = _camera_rays(W, H)
+    hit, tmin, tmax = _slab(o, d)
+    cls = t[..., 5].astype(int)
+    t_left = t[..., 4].astype(np.float64)
+    packed = t[..., 3].view(np.uint32)
+    segs, draws = (packed & 0xffff).astype(int), (packed >> 16).astype(int)
+    assert set(np.unique(cls)) == {0, 1, 2}
+    decided = np.abs(tmax - tmin) > 1e-4
+    assert np.array_equal((cls == 2)[decided], ~hit[decided])
+    # non-empty cells of the volume: any texel of the clamped 2x2x2 neighbourhood non-zero
+    g = np.pad(grid, ((0, 1), (0, 1), (0, 1)), mode="edge") != 0
+    cell_nonempty = np.zeros((n, n, n), bool)
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                cell_nonempty |= g[dz:dz + n, dy:dy + n, dx:dx + n]
+    if est:
+        # the restart crawl in front of the volume: origin moved by segs * 0.05, still outside by more than a segment
+        walked = segs * 0.05
+        want = o + d * walked[..., None]
+        assert np.abs(t[..., :3] - want).max() < 2e-4
+        assert np.all(draws == segs)
+        front = hit & (tmin > 0)
+        assert np.all((tmin - walked)[front] <= 0.05 + 1e-4) and np.all((tmin - walked)[front] > -1e-4)
+        assert segs[hit].mean() > 30 and np.all(segs[~hit & decided] == 0)
+        start = walked
+    else:
+        assert np.all(segs == 0)
+        start = np.zeros_like(tmin)
+    # (a): dense sampling (1/20 cell) of [box entry, certified distance)
+    ys, xs = np.nonzero(hit & (t_left > 0))
+    pick = rng.choice(len(ys), 400, replace=False)
+    cell = 2.0 / n
+    checked = 0
+    for y, x in zip(ys[pick], xs[pick]):
+        t0 = max(tmin[y, x], 0.0)
+        t1 = min(start[y, x] + t_left[y, x], tmax[y, x])
+        if t1 <= t0:
+            continue
+        tt = np.arange(t0, t1, cell / 20)
+        p = (o[y, x] + d[y, x] * tt[:, None] + 1.0) / 2.0 * n - 0.5
+        idx = np.clip(np.floor(np.maximum(p, 0)).astype(int), 0, n - 1)
+        assert not cell_nonempty[idx[:, 2], idx[:, 1], idx[:, 0]].any(), (y, x)
+        checked += len(tt)
+        if cls[y, x] == 1:
+            assert t_left[y, x] > 1e29
+    assert checked > 100000
+    # the certificate is not vacuous: most box-hitting rays get one, and a good share of them is certified to the end
+    assert (t_left[hit] > 0).mean() > 0.8 and (cls[hit] == 1).mean() > 0.3
