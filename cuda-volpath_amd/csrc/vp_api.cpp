@@ -81,7 +81,7 @@ struct State
     unsigned*   d_queue       = nullptr;
     unsigned long long* d_counters = nullptr;
     bool        count       = false;
-    unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS, setup_lanes = VP_SETUP_LANES;
+    unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS, setup_lanes = VP_SETUP_LANES, light_wait_iters = 64;
     unsigned    blocks_per_cu = 6;  // resident 256-thread workgroups per CU (the register budget of each kernel decides how many really are)
     bool        use_lds_bounds = true;
     // where the restart crawl in front of the volume ends, per pixel (crawl_table_k); rebuilt when what it depends on changes
@@ -89,6 +89,8 @@ struct State
     bool        use_empty_table = true;   // global-majorant estimator: certified-empty distances of the camera rays
     bool        use_light   = true;       // ... and the light kernel for pixels whose ray meets empty cells only
     bool        use_light_local = true;   // ... also for the local-majorant estimators
+    int         debug_only_class = -1;    // VP_DEBUG_ONLY_CLASS = 0 / 1: launch only the general / only the light kernel (INCOMPLETE images;
+                                          // for the block tallies of one kernel)
     // the pixels this context owns (those of its tiles), class by class: [general..., light...], each y << 16 | x
     unsigned*   d_tiles     = nullptr;
     size_t      tiles_cap   = 0;
@@ -201,6 +203,7 @@ int ensure_device()
     if (knob("VP_WAIT_LANES", 1, 64, v)) G.wait_lanes = (unsigned)v;
     if (knob("VP_WAIT_ITERS", VP_STEPS_PER_PASS, 1 << 20, v)) G.wait_iters = (unsigned)v;
     if (knob("VP_SETUP_LANES", 1, 64, v)) G.setup_lanes = (unsigned)v;
+    if (knob("VP_LIGHT_WAIT_ITERS", VP_STEPS_PER_PASS, 1 << 20, v)) G.light_wait_iters = (unsigned)v;
     if (knob("VP_STAGE_MB", 1, 256 << 10, v)) G.max_stage_bytes = (size_t)v << 20;
     if (knob("VP_BLOCKS_PER_CU", 1, 8, v)) G.blocks_per_cu = (unsigned)v;
     if (knob("VP_NO_LDS_BOUNDS", 0, 1, v)) G.use_lds_bounds = v == 0;
@@ -209,6 +212,7 @@ int ensure_device()
     if (knob("VP_NO_LIGHT", 0, 1, v)) G.use_light = v == 0;
     if (knob("VP_NO_LIGHT_OVERLAP", 0, 1, v)) G.light_overlap = v == 0;
     if (knob("VP_NO_LIGHT_LOCAL", 0, 1, v)) G.use_light_local = v == 0;
+    if (knob("VP_DEBUG_ONLY_CLASS", 0, 1, v)) G.debug_only_class = (int)v;
     if (knob("VP_GENERAL_BLOCKS_PER_CU", 1, 8, v)) G.general_blocks_per_cu = (unsigned)v;
     if (knob("VP_LIGHT_BLOCKS_PER_CU", 1, 8, v)) G.light_blocks_per_cu = (unsigned)v;
     if (knob("VP_LOOKAHEAD", 0, 4096, v)) G.la_max = (int)v;
@@ -659,6 +663,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         {
             const unsigned nt = cls ? G.n_light : G.n_general;
             if (!nt) continue;
+            if (G.debug_only_class >= 0 && G.debug_only_class != cls) continue;  // VP_DEBUG_ONLY_CLASS: block tallies of one kernel
             L.pixels      = G.d_tiles + (cls ? G.n_general : 0);
             L.nslots      = nt;
             L.slot_base   = cls ? G.n_general : 0u;
@@ -676,6 +681,9 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             if (both && !cls) bpc = G.general_blocks_per_cu ? G.general_blocks_per_cu : (G.est == VP_EST_GLOBAL ? 3u : 5u);
             unsigned cap    = (unsigned)G.num_cu * (ldsb ? 2u : bpc);
             if (blocks > cap) blocks = cap;
+            // the light kernel's paths are long and end rarely: its waves leave the tracking loop for the (refill / environment /
+            // write) pass less often than the general kernel's do for their collisions
+            L.wait_iters = cls ? G.light_wait_iters : G.wait_iters;
             if (cls)
             {
                 // the light kernel: beside the general one on the target's auxiliary stream when both classes have work
