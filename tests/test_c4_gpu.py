@@ -261,3 +261,34 @@ def test_event_ring_stays_bounded_and_oom_is_reported(vp, oracle):
     vp.render_frames(buf.ptr, 0, 2, vp.make_param(W, H))
     assert np.isfinite(buf.download()).all()
     buf.free()
+
+
+def test_tuning_knobs_are_validated_and_never_change_results(tmp_path):
+    """VP_WAIT_LANES=0 used to hang the persistent kernel, VP_BLOCKS_PER_CU=0 was an empty launch.  Out-of-range or
+    malformed values are ignored with a message; valid ones change speed, never bits (here: the per-pixel tables, the light
+    kernel and its overlap switched off one by one)."""
+    import hashlib
+    import sys
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, volpath as vp, scenes\n"
+        "vp.set_device(0); W, H = 72, 40\n"
+        "out = []\n"
+        "for est in (0, 1):\n"
+        "    vp.init_volume(vp.julia_volume(32), brick=4 if est else 1); vp.init_envmap(scenes.synthetic_env())\n"
+        "    vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER); vp.set_camera(); vp.set_estimator(est)\n"
+        "    vp.set_rng(vp.RNG_PHILOX, (3, 1)); b = vp.DeviceBuffer(W, H); vp.render_frames(b.ptr, 0, 6, vp.make_param(W, H))\n"
+        "    out.append(hashlib.sha1(b.download().tobytes()).hexdigest())\n"
+        "print('HASH', *out)\n"
+    ) % (os.path.join(ROOT, "cuda-volpath_amd"), os.path.join(ROOT, "tests"))
+    hashes = {}
+    for name, env in (("default", {}), ("bad", {"VP_WAIT_LANES": "0", "VP_BLOCKS_PER_CU": "0", "VP_STAGE_MB": "-5", "VP_WAIT_ITERS": "x"}),
+                      ("no_tables", {"VP_NO_CRAWL_TABLE": "1", "VP_NO_EMPTY_TABLE": "1"}), ("no_light", {"VP_NO_LIGHT": "1"}),
+                      ("no_overlap", {"VP_NO_LIGHT_OVERLAP": "1", "VP_SETUP_LANES": "1", "VP_WAIT_LANES": "32"})):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        hashes[name] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
+        if name == "bad":
+            assert r.stderr.count("ignoring VP_") == 4, r.stderr
+    assert len(set(hashes.values())) == 1, hashes

@@ -165,3 +165,21 @@ def test_bench_cpu_baseline_leg_runs_for_every_estimator(host):
     spec.loader.exec_module(bench)
     r = bench.cpu_baseline("c1", seconds_hint=60.0)      # Julia 128^3, 400x300, decomposition: 16 frames incl. 11..15
     assert r["kind"] == "port" and r["value"] > 0 and "frames 0..15" in r["sample"] and "not affordable" not in r["sample"]
+
+
+def test_truncated_volume_files_are_errors(host, tmp_path):
+    """a short .bin / raw file must not yield a volume with an uninitialised tail (the reference returns one)."""
+    import ctypes as C
+    vol = np.arange(4 * 5 * 6, dtype=np.float32).reshape(6, 5, 4) / 200.0
+    full = str(tmp_path / "full.bin")
+    assert host.dump_dense(full, vol)
+    assert host.load_binary(full, quantized=False).shape == (6, 5, 4)
+    raw = open(full, "rb").read()
+    cut = str(tmp_path / "cut.bin")
+    open(cut, "wb").write(raw[:-40])
+    assert host.load_binary(cut) is None and host.load_binary(cut, quantized=False) is None
+    open(cut, "wb").write(raw[:8])                       # not even the three dimensions
+    assert host.load_binary(cut) is None
+    L = host.lib()
+    assert L.vph_load_raw(cut.encode(), C.c_size_t(8))    # exactly the bytes that are there: fine
+    assert not L.vph_load_raw(cut.encode(), C.c_size_t(64))
