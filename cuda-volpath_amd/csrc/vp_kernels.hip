@@ -5,7 +5,11 @@
 // its neighbours keep tracking; every path carries its own RNG state and therefore computes the
 // same bits wherever and whenever it runs.  A wave alternates between an inner loop of free-flight
 // steps (four per pass; segment set-up included for the local-majorant estimators) and an event
-// pass that serves the lanes parked on collisions, light estimates, exits and refills.  Restates
+// pass that serves the lanes parked on collisions, light estimates, exits and refills.  What depends on a pixel's camera
+// ray alone (the same ray in every frame) is tabulated once per pixel -- the restart crawl in front of the volume, the
+// distance up to which the ray meets only empty cells, the pixel's class -- and pixels whose ray never meets a non-empty
+// cell run the LIGHT specialisation of the kernel beside the general one (crawl_table_k, empty_table_k).
+// Restates
 //   __d_render_bounded_decomp  kernel.cu:1958-2318  (EST_DECOMP, the reference's live kernel)
 //   __d_render                 kernel.cu:1285-1591  (EST_GLOBAL, BASELINE config 2)
 //   __d_render_bounded         kernel.cu:1667-1952  (EST_BOUNDED, dead in the reference)
