@@ -81,7 +81,7 @@ struct State
     unsigned*   d_queue       = nullptr;
     unsigned long long* d_counters = nullptr;
     bool        count       = false;
-    unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS, setup_lanes = VP_SETUP_LANES, light_wait_iters = 64;
+    unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS, setup_lanes = VP_SETUP_LANES, light_wait_iters = 0;  // 0 = by estimator
     unsigned    blocks_per_cu = 6;  // resident 256-thread workgroups per CU (the register budget of each kernel decides how many really are)
     bool        use_lds_bounds = true;
     // where the restart crawl in front of the volume ends, per pixel (crawl_table_k); rebuilt when what it depends on changes
@@ -108,6 +108,10 @@ struct State
     float4*     d_crawl     = nullptr;
     size_t      crawl_bytes = 0;
     std::vector<unsigned char> crawl_key;
+    float*      d_thr       = nullptr;    // throughput after n null collisions in empty space (light kernel, global majorant)
+    float       thr_key[5]  = {};
+    bool        thr_valid   = false;
+    unsigned    thr_entries = 4096;       // paths with more null collisions run the recurrence on from the last entry (VP_THR_TABLE)
     // launch timing: a ring of the last kMaxPendingEvents launches; older pairs are folded into the running sum
     std::deque<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> event_pool;
@@ -215,6 +219,7 @@ int ensure_device()
     if (knob("VP_DEBUG_ONLY_CLASS", 0, 1, v)) G.debug_only_class = (int)v;
     if (knob("VP_GENERAL_BLOCKS_PER_CU", 1, 8, v)) G.general_blocks_per_cu = (unsigned)v;
     if (knob("VP_LIGHT_BLOCKS_PER_CU", 1, 8, v)) G.light_blocks_per_cu = (unsigned)v;
+    if (knob("VP_THR_TABLE", 2, 1 << 20, v)) G.thr_entries = (unsigned)v;
     if (knob("VP_LOOKAHEAD", 0, 4096, v)) G.la_max = (int)v;
     G.dev_ready = true;
     return VP_OK;
@@ -523,6 +528,29 @@ int ensure_crawl_table(const Param* p, const float4** out)
     return VP_OK;
 }
 
+// The light kernel of the global-majorant estimator looks the throughput of a path up by its number of null collisions
+// (vp_kernels.hip thr_table_k); the sequence depends on sigma_t, density and g only.
+int ensure_thr_table(const Param* p, const float** out)
+{
+    *out = nullptr;
+    const float key[5] = {p->sigma_t.x, p->sigma_t.y, p->sigma_t.z, p->density, p->g};
+    if (!G.thr_valid || !G.d_thr || memcmp(key, G.thr_key, sizeof key) != 0)
+    {
+        if (la_quiesce()) return VP_E_NODEVICE;   // batches in flight read the old table
+        HIPCHK(hipStreamSynchronize(G.stream));
+        if (!G.d_thr) HIPCHK(hipMalloc((void**)&G.d_thr, G.thr_entries * sizeof(float)));
+        ParamDev P;
+        memcpy(&P, p, sizeof(Param));
+        launch_thr_table(P, G.d_thr, G.thr_entries, G.stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(G.stream));
+        memcpy(G.thr_key, key, sizeof key);
+        G.thr_valid = true;
+    }
+    *out = G.d_thr;
+    return VP_OK;
+}
+
 // The pixel lists of this context: the pixels of its tiles, tile by tile (row-major tiles, row-major pixels within a tile: the
 // order keeps the rays of a wave in one pencil of the volume), general pixels first, then -- with spectral tracking and a pixel
 // table -- the light class (camera rays that meet certified-empty cells over their whole chord) and the pixels whose camera ray
@@ -615,6 +643,12 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     if (rc) return rc;
     rc = ensure_pixel_lists(p, L.crawl, sh);
     if (rc) return rc;
+    if (G.est == VP_EST_GLOBAL && G.n_light)
+    {
+        rc = ensure_thr_table(p, &L.thr_table);
+        if (rc) return rc;
+        L.thr_n = G.thr_entries;
+    }
     const size_t per_frame = sh.per_frame;
     if (0xfffffff0u / per_frame < 1) return fail(VP_E_ARG, "image too large for the 32-bit sample queue");
     L.stage_stride = (unsigned)per_frame;
@@ -677,13 +711,16 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             unsigned blocks = (waves + (bsz / 64) - 1) / (bsz / 64);
             const bool     both = G.n_light && G.n_general;
             unsigned       bpc  = G.blocks_per_cu;
-            if (both && cls) bpc = G.light_blocks_per_cu ? G.light_blocks_per_cu : (G.est == VP_EST_GLOBAL ? 4u : 2u);
-            if (both && !cls) bpc = G.general_blocks_per_cu ? G.general_blocks_per_cu : (G.est == VP_EST_GLOBAL ? 3u : 5u);
+            // what fits a SIMD's 512 vector registers side by side: global majorant 4 x 80 (achromatic; 88 otherwise) + 3 (2) x 64,
+            // local majorant 5 x 96 + ... the light kernel's blocks take what is left as general blocks retire
+            const bool ach = p->sigma_t.x == p->sigma_t.y && p->sigma_t.y == p->sigma_t.z && p->albedo.x == p->albedo.y && p->albedo.y == p->albedo.z;
+            if (both && cls) bpc = G.light_blocks_per_cu ? G.light_blocks_per_cu : (G.est == VP_EST_GLOBAL ? (ach ? 3u : 2u) : 2u);
+            if (both && !cls) bpc = G.general_blocks_per_cu ? G.general_blocks_per_cu : (G.est == VP_EST_GLOBAL ? 4u : 5u);
             unsigned cap    = (unsigned)G.num_cu * (ldsb ? 2u : bpc);
             if (blocks > cap) blocks = cap;
             // the light kernel's paths are long and end rarely: its waves leave the tracking loop for the (refill / environment /
             // write) pass less often than the general kernel's do for their collisions
-            L.wait_iters = cls ? G.light_wait_iters : G.wait_iters;
+            L.wait_iters = cls ? (G.light_wait_iters ? G.light_wait_iters : (G.est == VP_EST_GLOBAL ? 128u : 64u)) : G.wait_iters;
             if (cls)
             {
                 // the light kernel: beside the general one on the target's auxiliary stream when both classes have work
@@ -1010,6 +1047,7 @@ int vp_ctx_destroy(vp_ctx* ctx)
         for (auto e : D.event_pool) (void)hipEventDestroy(e);
         if (D.d_stage) (void)hipFree(D.d_stage);
         if (D.d_crawl) (void)hipFree(D.d_crawl);
+        if (D.d_thr) (void)hipFree(D.d_thr);
         if (D.d_tiles) (void)hipFree(D.d_tiles);
         for (int i = 0; i < 3; i++)
         {
@@ -1200,6 +1238,21 @@ int vp_get_pixel_table(const Param* p, float* dst, size_t count)
     if (rc) return rc;
     if (!t) return fail(VP_E_STATE, "no pixel table in this configuration (point filtering, or the tables are switched off)");
     HIPCHK(hipMemcpy(dst, t, need * sizeof(float), hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+int vp_get_null_collision_table(const Param* p, float* dst, size_t count)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !dst || !count || count > (1u << 24)) return fail(VP_E_ARG, "vp_get_null_collision_table: bad argument");
+    struct Tmp { float* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } tmp;
+    HIPCHK(hipMalloc((void**)&tmp.p, count * sizeof(float)));
+    ParamDev P;
+    memcpy(&P, p, sizeof(Param));
+    launch_thr_table(P, tmp.p, (unsigned)count, G.stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(G.stream));
+    HIPCHK(hipMemcpy(dst, tmp.p, count * sizeof(float), hipMemcpyDeviceToHost));
     return VP_OK;
 }
 int vp_get_opacity(float* dst, size_t count)

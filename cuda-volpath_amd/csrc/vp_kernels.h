@@ -33,6 +33,12 @@
 #define VP_SETUP_LANES 8
 #endif
 // tracking steps per pass of the inner loop: the wave-level bookkeeping (ballots, wait policy) is paid once per pass
+#ifndef VP_LIGHT_MIN_WAVES
+#define VP_LIGHT_MIN_WAVES 6
+#endif
+#ifndef VP_LIGHT_STEPS_PER_PASS
+#define VP_LIGHT_STEPS_PER_PASS 16
+#endif
 #ifndef VP_STEPS_PER_PASS
 #define VP_STEPS_PER_PASS 4
 #endif
@@ -70,6 +76,8 @@ struct LaunchDev
     unsigned key0, key1;    // Philox key
     unsigned wait_lanes, wait_iters;  // inner-loop exit policy (VP_WAIT_LANES / VP_WAIT_ITERS)
     unsigned setup_lanes;   // lanes that must ask for a segment set-up before it runs mid-pass (VP_SETUP_LANES; 1 = at every step)
+    const float* thr_table; // light kernel of the global-majorant estimator: thr_table[n] = throughput after n null collisions in empty
+    unsigned thr_n;         // space (thr_table_k: a function of n alone there), n < thr_n; beyond the table the recurrence is run
 };
 
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
@@ -77,6 +85,8 @@ void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool
 // the light pixel class (spectral tracking): pixels whose camera ray meets empty cells only
 void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int blocks, hipStream_t st);
 void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimator, hipStream_t st);
+// throughput of an unscattered global-majorant path after n null collisions with density +0, n = 0..count-1 (thr_table_k)
+void launch_thr_table(const ParamDev& P, float* table, unsigned count, hipStream_t st);
 void launch_pixel_classes(const float4* table, unsigned npixels, unsigned char* out, hipStream_t st);
 void launch_env_tables(const float4* env, int w, int h, float* lum, float* row_sum, float* cdf_x, float* cdf_y, float* pdfnorm_alt,
                        hipStream_t st);

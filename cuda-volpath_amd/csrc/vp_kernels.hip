@@ -46,6 +46,34 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+// One null collision of the spectral tracker where the density is +0 (kernel.cu:2107-2134 with sigma_t_den = +0: Ps = +0, c = Pn,
+// `real` false for any draw, sigma_null_den = sigma_t'), for a throughput with three equal channels t:
+// Pn = (m + m) + m with m = |sigma_t' t|, t *= sigma_t' * ((inv_sigma_t * Pn) / Pn).  The factor is 1 up to rounding, not exactly.
+__device__ __forceinline__ float null_collision_in_empty_space(float t, float sigma_t_prime, float inv_sigma_t)
+{
+    float mn = __builtin_fabsf(sigma_t_prime * t);
+    float Pn = (mn + mn) + mn;
+    return t * (sigma_t_prime * wdiv_(inv_sigma_t * Pn, Pn));
+}
+// table[n] = throughput of an unscattered path of the global-majorant estimator after n null collisions in empty space: it
+// starts at (1,1,1) and every sample has the same sigma_t' (segment set-up of __d_render with no scatter behind it,
+// kernel.cu:1355-1366), so the sequence is the same for every sample of a launch.  One thread, `count` dependent steps.
+__global__ void thr_table_k(ParamDev P, float* table, unsigned count)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const float max_sig       = max3(f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]});
+    const float s             = hyperion_s(0 - 5);
+    const float cur_density   = (1.0f - s) * P.density + s * P.density * (1.0f - P.g);
+    const float sigma_t_prime = max_sig * cur_density;
+    const float inv_sigma_t   = 1.0f / sigma_t_prime;
+    float t = 1.0f;
+    for (unsigned n = 0; n < count; n++)
+    {
+        table[n] = t;
+        t = null_collision_in_empty_space(t, sigma_t_prime, inv_sigma_t);
+    }
+}
+
 // LDSB: the (max,min) brick table of the decomposition estimator is staged through LDS (BASELINE config 3:
 // 256^3 / 8^3 bricks = 32768 byte pairs = 64 KiB).  Those workgroups are 512 threads so that two of them
 // (2 x 64 KiB of the CU's 160 KiB) keep 16 waves per CU resident.
@@ -65,7 +93,7 @@ template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool 
 // asking for five costs no spill and is +10 % on the reference-table decomposition workload.  The global-majorant
 // kernel fits six waves (80 VGPRs, no spill): +3 % now that the queue order keeps the L2 hit rate above 90 %.
 __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK,
-                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (MIS || LDSB ? 1 : (EST == EST_GLOBAL && ACH && TRK == 0 ? 6 : 5)))
+                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT && EST == EST_GLOBAL ? VP_LIGHT_MIN_WAVES : MIS || LDSB ? 1 : (EST == EST_GLOBAL && ACH && TRK == 0 ? 6 : 5)))
 void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
@@ -352,6 +380,14 @@ void render_k(SceneDev S, LaunchDev L)
                     f3 bg;
                     if (nsc == 0 && dot(rd, sun_dir) > S.sun_cos) bg = f3{S.sun_orig[0], S.sun_orig[1], S.sun_orig[2]};
                     else { bg = eval_envmap(S, rd); if (COUNT) c_env++; }
+                    if (LIGHT && !LOCAL)
+                    {
+                        // throughput after `seg` null collisions in empty space (see tracking_step)
+                        const unsigned n = (unsigned)seg, last = L.thr_n - 1u;
+                        float t = L.thr_table[n < last ? n : last];
+                        for (unsigned k = last; k < n; k++) t = null_collision_in_empty_space(t, sigma_t_prime, inv_sigma_t);
+                        thr = f3{t, t, t};
+                    }
                     rad = rad + bg * (ACH ? f3{thr.x, thr.x, thr.x} : thr);
                 }
                 st = EV_WRITE;
@@ -576,19 +612,11 @@ void render_k(SceneDev S, LaunchDev L)
                         // (sampler.h) must still move past it; for the counter-based streams this is nothing
                         (void)rng.next_b();
                         if (COUNT) c_den++;
-                        if (ACH)
-                        {
-                            float mn = __builtin_fabsf(sigma_t_prime * thr.x);
-                            float Pn = (mn + mn) + mn;
-                            thr.x    = thr.x * (sigma_t_prime * wdiv_(inv_sigma_t * Pn, Pn));
-                        }
-                        else
-                        {
-                            float Pn = __builtin_fabsf(sigma_t_prime * thr.x) + __builtin_fabsf(sigma_t_prime * thr.y) +
-                                       __builtin_fabsf(sigma_t_prime * thr.z);
-                            float sf = sigma_t_prime * wdiv_(inv_sigma_t * Pn, Pn);
-                            thr      = thr * f3{sf, sf, sf};
-                        }
+                        // The throughput update of this null collision, thr *= sigma_t' * ((inv_sigma_t * Pn) / Pn) with
+                        // Pn = |sigma_t' thr.x| + |sigma_t' thr.y| + |sigma_t' thr.z|, draws nothing and starts from (1,1,1) with the
+                        // same sigma_t' in every sample: after n null collisions the throughput is the n-th iterate of one
+                        // function of one float (three equal channels), tabulated by thr_table_k.  Count here, look up at the exit.
+                        seg++;
                     }
                 }
                 return;
@@ -729,8 +757,11 @@ void render_k(SceneDev S, LaunchDev L)
                 }
             }
         };
+        // the light kernel of the global-majorant estimator has the shortest step (a draw, a logarithm, an add and a compare):
+        // more of them per round of wave-level bookkeeping
+        constexpr int STEPS = (LIGHT && !LOCAL) ? VP_LIGHT_STEPS_PER_PASS : VP_STEPS_PER_PASS;
 #pragma unroll 1
-        for (int iter = 0;; iter += VP_STEPS_PER_PASS)
+        for (int iter = 0;; iter += STEPS)
         {
             bool active = (st == ST_TRACK) || (st == ST_SHADOW) || (LOCAL && st == ST_SETUP);
             unsigned long long am = __ballot(active);
@@ -742,7 +773,7 @@ void render_k(SceneDev S, LaunchDev L)
             segment_setup();
             tracking_step();
 #pragma unroll
-            for (int u = 1; u < VP_STEPS_PER_PASS; u++)
+            for (int u = 1; u < STEPS; u++)
             {
                 if (COUNT)
                 {
@@ -1328,6 +1359,8 @@ static void launch_render_p7(const SceneDev& S, const LaunchDev& L, bool quant, 
 template <int EST, class RNGT>
 static void launch_light2(const SceneDev& S, const LaunchDev& L, bool quant, bool count, bool ach, int blocks, hipStream_t st)
 {
+    // the global-majorant light kernel carries one throughput channel whatever the medium (thr_table_k): one instance serves both
+    if (EST == EST_GLOBAL) ach = true;
     const dim3 g(blocks), b(VP_BLOCK);
     // QUANT only selects how the bound table of the local-majorant estimators is read; the light kernels fetch no cells
     constexpr bool LOC = EST != EST_GLOBAL;
@@ -1335,12 +1368,12 @@ static void launch_light2(const SceneDev& S, const LaunchDev& L, bool quant, boo
     if (LOC && !quant)
     {
         if (ach) { if (count) VP_LL(false, true, true); else VP_LL(false, false, true); }
-        else { if (count) VP_LL(false, true, false); else VP_LL(false, false, false); }
+        else if constexpr (LOC) { if (count) VP_LL(false, true, false); else VP_LL(false, false, false); }
     }
     else
     {
         if (ach) { if (count) VP_LL(true, true, true); else VP_LL(true, false, true); }
-        else { if (count) VP_LL(true, true, false); else VP_LL(true, false, false); }
+        else if constexpr (LOC) { if (count) VP_LL(true, true, false); else VP_LL(true, false, false); }
     }
 #undef VP_LL
 }
@@ -1371,6 +1404,10 @@ void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng
     else VP_LE(RngSamplerH);
 #endif
 #undef VP_LE
+}
+void launch_thr_table(const ParamDev& P, float* table, unsigned count, hipStream_t st)
+{
+    hipLaunchKernelGGL(thr_table_k, dim3(1), dim3(64), 0, st, P, table, count);
 }
 void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimator, hipStream_t st)
 {

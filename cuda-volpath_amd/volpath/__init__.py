@@ -24,7 +24,7 @@ PART1_SYMBOLS = ["init_cuda", "set_texture_filter_mode", "free_cuda_buffers", "p
                  "render_kernel", "scale", "gamma_correct"]
 PART2_SYMBOLS = ["vp_last_error", "vp_version", "vp_device_count", "vp_set_device", "vp_set_stream", "vp_get_stream", "vp_synchronize",
                  "vp_set_estimator", "vp_set_rng", "vp_set_envmap_sampling", "vp_get_env_tables", "vp_set_lookahead", "vp_set_tracking", "vp_set_bound_brick", "vp_set_shard", "vp_render_frames",
-                 "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity", "vp_get_pixel_table",
+                 "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity", "vp_get_pixel_table", "vp_get_null_collision_table",
                  "vp_julia_voxelize", "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_test_hg", "vp_test_intersect_box",
                  "vp_test_eval_envmap", "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_current", "vp_ctx_get_current", "vp_ctx_device",
                  "vp_accumulate", "vp_tile_owner", "vp_malloc", "vp_free", "vp_memset",
@@ -89,6 +89,7 @@ def lib():
         L.vp_get_bound_table.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 5
         L.vp_get_opacity.argtypes = [C.c_void_p, C.c_size_t]
         L.vp_get_pixel_table.argtypes = [C.POINTER(Param), C.c_void_p, C.c_size_t]
+        L.vp_get_null_collision_table.argtypes = [C.POINTER(Param), C.c_void_p, C.c_size_t]
         L.vp_julia_voxelize.argtypes = [C.c_int, C.c_void_p]
         L.vp_test_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.vp_test_rng.argtypes = [C.c_int] + [C.c_uint32] * 5 + [C.c_int, C.c_void_p]
@@ -317,6 +318,13 @@ def pixel_table(P):
     """(H, W, 8) float32: crawl end xyz, packed counts (view as uint32), certified-empty distance, 3 unused"""
     out = np.empty((P.height, P.width, 8), np.float32)
     _chk(lib().vp_get_pixel_table(C.byref(P), _p(out), out.size))
+    return out
+
+
+def null_collision_table(P, count):
+    """float32[count]: throughput of an unscattered global-majorant path after n null collisions in empty space"""
+    out = np.empty(count, np.float32)
+    _chk(lib().vp_get_null_collision_table(C.byref(P), _p(out), out.size))
     return out
 
 

@@ -198,6 +198,10 @@ int vp_get_opacity(float* dst, size_t count);
  * [3] its segment and draw counts (bits: segments | draws << 16), [4] the distance from there up to which the camera ray is
  * certified to meet only empty cells, [5..7] unused.  Test hook for the certificates. */
 int vp_get_pixel_table(const Param* p, float* dst, size_t count);
+/* dst[n] = throughput of an unscattered path of the global-majorant estimator after n null collisions in empty space, n < count
+ * (spectral tracking: the weight of such a collision is 1 only up to rounding; the light kernel looks the product up by n).
+ * Test hook: the sequence is three float32 operations per step and can be restated anywhere. */
+int vp_get_null_collision_table(const Param* p, float* dst, size_t count);
 
 /* building blocks exposed for parity tests (device execution, host arrays) */
 int vp_test_math(int which, const float* in, float* out, int n);

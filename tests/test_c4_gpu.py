@@ -266,7 +266,7 @@ def test_event_ring_stays_bounded_and_oom_is_reported(vp, oracle):
 def test_tuning_knobs_are_validated_and_never_change_results(tmp_path):
     """VP_WAIT_LANES=0 used to hang the persistent kernel, VP_BLOCKS_PER_CU=0 was an empty launch.  Out-of-range or
     malformed values are ignored with a message; valid ones change speed, never bits (here: the per-pixel tables, the light
-    kernel and its overlap switched off one by one)."""
+    kernel and its overlap switched off one by one, a two-entry null-collision table on a medium whose weights are not 1)."""
     import hashlib
     import sys
     code = (
@@ -277,14 +277,15 @@ def test_tuning_knobs_are_validated_and_never_change_results(tmp_path):
         "for est in (0, 1):\n"
         "    vp.init_volume(vp.julia_volume(32), brick=4 if est else 1); vp.init_envmap(scenes.synthetic_env())\n"
         "    vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER); vp.set_camera(); vp.set_estimator(est)\n"
-        "    vp.set_rng(vp.RNG_PHILOX, (3, 1)); b = vp.DeviceBuffer(W, H); vp.render_frames(b.ptr, 0, 6, vp.make_param(W, H))\n"
+        "    vp.set_rng(vp.RNG_PHILOX, (3, 1)); b = vp.DeviceBuffer(W, H); vp.render_frames(b.ptr, 0, 6, vp.make_param(W, H, density=209.0, sigma_t=(0.3, 0.7, 1.0), albedo=(0.9, 0.8, 0.95)))\n"
         "    out.append(hashlib.sha1(b.download().tobytes()).hexdigest())\n"
         "print('HASH', *out)\n"
     ) % (os.path.join(ROOT, "cuda-volpath_amd"), os.path.join(ROOT, "tests"))
     hashes = {}
     for name, env in (("default", {}), ("bad", {"VP_WAIT_LANES": "0", "VP_BLOCKS_PER_CU": "0", "VP_STAGE_MB": "-5", "VP_WAIT_ITERS": "x"}),
                       ("no_tables", {"VP_NO_CRAWL_TABLE": "1", "VP_NO_EMPTY_TABLE": "1"}), ("no_light", {"VP_NO_LIGHT": "1"}),
-                      ("no_overlap", {"VP_NO_LIGHT_OVERLAP": "1", "VP_SETUP_LANES": "1", "VP_WAIT_LANES": "32"})):
+                      ("no_overlap", {"VP_NO_LIGHT_OVERLAP": "1", "VP_SETUP_LANES": "1", "VP_WAIT_LANES": "32"}),
+                      ("short_table", {"VP_THR_TABLE": "2", "VP_LIGHT_WAIT_ITERS": "16", "VP_LIGHT_BLOCKS_PER_CU": "1"})):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr

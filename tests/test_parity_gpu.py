@@ -89,14 +89,18 @@ def test_julia64_chromatic_bricks(vp, oracle, brick):
     buf.free()
 
 
+@pytest.mark.parametrize("density", [800.0, 209.0])
 @pytest.mark.parametrize("rng_mode", [0, 1, 2])
-def test_global_majorant_chromatic_light_and_general_pixels(vp, oracle, rng_mode):
+def test_global_majorant_chromatic_light_and_general_pixels(vp, oracle, rng_mode, density):
     """Global-majorant estimator on a chromatic medium (the null-collision weights are not exactly 1, so the throughput of a
     path depends on how many steps it took): pixels whose camera ray meets only empty cells run the light kernel, the others
     the general one, side by side.  Image and work counters == oracle for the sequential sampler.h stream (whose unused
-    collision variate must still be consumed) and both counter-based ones; the pixel table holds all three classes."""
+    collision variate must still be consumed) and both counter-based ones; the pixel table holds all three classes.
+    Density 209: a majorant for which the weight of a null collision in EMPTY space is one ulp below 1 (at 800 it is exactly 1),
+    so the light kernel's throughput table (thr_table_k) is not a row of ones."""
     grid = oracle.julia(64)
-    osc, oP, vP = _setup(vp, oracle, grid, 0, rng_mode, brick=1, preset=scenes.PRESET1, key=(5, 77))
+    osc, oP, vP = _setup(vp, oracle, grid, 0, rng_mode, brick=1, preset=scenes.PRESET1, key=(5, 77), P_kw=dict(density=density))
+    assert (vp.null_collision_table(vP, 64)[-1] != 1.0) == (density == 209.0)
     t = vp.pixel_table(vP)
     classes = np.bincount(t[..., 5].astype(int).ravel(), minlength=3)
     assert classes.min() > 50, classes                      # general, certified-empty and box-missing pixels all occur

@@ -454,3 +454,35 @@ def test_pixel_table_certificates_hold_in_float64(vp, est):
     assert checked > 100000
     # the certificate is not vacuous: most box-hitting rays get one, and a good share of them is certified to the end
     assert (t_left[hit] > 0).mean() > 0.8 and (cls[hit] == 1).mean() > 0.3
+
+
+def test_null_collision_table_is_the_float32_recurrence(vp):
+    """The light kernel of the global-majorant estimator looks a path's throughput up by its number of null collisions in empty
+    space (vp_kernels.hip thr_table_k).  The table restated here in numpy binary32, operation by operation, from the reference's
+    expressions with density +0 (kernel.cu:1355-1366, :1419-1443: Ps = +0, c = Pn = |s t| + |s t| + |s t|, t *= s * ((c / s') / c)
+    in the order the reference evaluates them).  No oracle involved.  The weight is exactly 1 for most media (800, the default,
+    among them) and one ulp off for about one in five (209, 246 here): there the throughput really depends on the step count."""
+    f = np.float32
+    moved = 0
+    for sigma_t, density, g in (((1, 1, 1), 800.0, 0.877), ((1, 1, 1), 333.3, 0.0), ((0.953, 1.0, 0.843), 800.0, 0.877),
+                                ((0.3, 0.7, 0.9), 57.3, -0.4), ((1, 1, 1), 1.0e-3, 0.5), ((1, 1, 1), 209.0, 0.877),
+                                ((0.3, 0.7, 1.0), 246.0, -0.4)):
+        P = vp.make_param(8, 8, density=density, g=g, sigma_t=sigma_t)
+        n = 6000   # beyond the 4096 entries the kernel keeps: same recurrence either way
+        got = vp.null_collision_table(P, n)
+        st = [f(P.sigma_t.x), f(P.sigma_t.y), f(P.sigma_t.z)]
+        s = f(max(f(0), min(f(1), f(-5) * f(0.066666666666666666667))))
+        cur = (f(1) - s) * f(P.density) + s * f(P.density) * (f(1) - f(P.g))
+        sp = max(st) * cur
+        inv = f(1) / sp
+        t = f(1)
+        ref = np.empty(n, f)
+        for k in range(n):
+            ref[k] = t
+            m = abs(sp * t)
+            pn = (m + m) + m
+            t = t * (sp * ((inv * pn) / pn))
+        assert np.array_equal(got, ref), (sigma_t, density, g, int(np.argmax(got != ref)))
+        assert abs(float(got[-1]) - 1.0) < 1e-3        # a rounding drift, not a physical attenuation
+        moved += int(got[-1] != 1.0)
+    assert moved >= 2
