@@ -127,7 +127,7 @@ struct RngPhiloxR
         for (int r = 0; r < ROUNDS; r++)
         {
             unsigned long long p = (unsigned long long)0xD256D193u * c0;
-            unsigned n0 = (unsigned)(p >> 32) ^ k ^ c1;
+            unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p >> 32), k, c1, 0x96);  // hi ^ k ^ c1 in one instruction (gfx950 V_BITOP3_B32)
             c1 = (unsigned)p;
             c0 = n0;
             k += 0x9E3779B9u;
