@@ -34,7 +34,7 @@
 #endif
 // tracking steps per pass of the inner loop: the wave-level bookkeeping (ballots, wait policy) is paid once per pass
 #ifndef VP_LIGHT_MIN_WAVES
-#define VP_LIGHT_MIN_WAVES 6
+#define VP_LIGHT_MIN_WAVES 8   // the light kernels fit 64 vector registers: two of their waves beside four of a 96-register kernel
 #endif
 #ifndef VP_LIGHT_STEPS_PER_PASS
 #define VP_LIGHT_STEPS_PER_PASS 16

@@ -93,7 +93,7 @@ template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool 
 // asking for five costs no spill and is +10 % on the reference-table decomposition workload.  The global-majorant
 // kernel fits six waves (80 VGPRs, no spill): +3 % now that the queue order keeps the L2 hit rate above 90 %.
 __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK,
-                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT && EST == EST_GLOBAL ? VP_LIGHT_MIN_WAVES : MIS || LDSB ? 1 : (EST == EST_GLOBAL && ACH && TRK == 0 ? 6 : 5)))
+                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : VP_LIGHT_MIN_WAVES) : MIS || LDSB ? 1 : (EST == EST_GLOBAL && ACH && TRK == 0 ? 6 : 5)))
 void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
@@ -1359,22 +1359,16 @@ static void launch_render_p7(const SceneDev& S, const LaunchDev& L, bool quant, 
 template <int EST, class RNGT>
 static void launch_light2(const SceneDev& S, const LaunchDev& L, bool quant, bool count, bool ach, int blocks, hipStream_t st)
 {
-    // the global-majorant light kernel carries one throughput channel whatever the medium (thr_table_k): one instance serves both
-    if (EST == EST_GLOBAL) ach = true;
+    // A light path never collides with matter: its throughput starts at (1,1,1) and every null collision in empty space multiplies
+    // the three channels by the same factor (sigma_t' - 0 in each), so they stay bitwise equal whatever the medium -- the
+    // one-channel (ACH) instance computes exactly what the three-channel one would.
     const dim3 g(blocks), b(VP_BLOCK);
     // QUANT only selects how the bound table of the local-majorant estimators is read; the light kernels fetch no cells
     constexpr bool LOC = EST != EST_GLOBAL;
 #define VP_LL(Q, C, A) hipLaunchKernelGGL((render_k<EST, RNGT, Q, C, false, A, false, 0, true>), g, b, 0, st, S, L)
-    if (LOC && !quant)
-    {
-        if (ach) { if (count) VP_LL(false, true, true); else VP_LL(false, false, true); }
-        else if constexpr (LOC) { if (count) VP_LL(false, true, false); else VP_LL(false, false, false); }
-    }
-    else
-    {
-        if (ach) { if (count) VP_LL(true, true, true); else VP_LL(true, false, true); }
-        else if constexpr (LOC) { if (count) VP_LL(true, true, false); else VP_LL(true, false, false); }
-    }
+    (void)ach;
+    if (LOC && !quant) { if (count) VP_LL(false, true, true); else VP_LL(false, false, true); }
+    else { if (count) VP_LL(true, true, true); else VP_LL(true, false, true); }
 #undef VP_LL
 }
 void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int blocks, hipStream_t st)
