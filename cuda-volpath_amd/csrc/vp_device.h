@@ -166,6 +166,20 @@ __device__ __forceinline__ void axis_linear(float pn, int n, int& i, float& fw)
     // the packed cell of voxel i already holds the clamped (i, i+1) pair
     i = i > n - 1 ? n - 1 : i;
 }
+// The same split for float texels, where the short cut above is not exact: below the first texel centre the two taps are the SAME
+// texel but the weight is still the fraction of the coordinate, and a*(1-w) + a*w is not a in binary32.  `low` tells the filter
+// to use the first tap twice (the packed cell of voxel 0 holds texels 0 and 1).
+__device__ __forceinline__ void axis_linear_f32(float pn, int n, int& i, float& fw, bool& low)
+{
+    float xb = fma_(pn, (float)n, -0.5f);
+    float fl = __builtin_floorf(xb);
+    float fr = xb - fl;
+    i        = (int)fl;
+    fw       = __builtin_floorf(fma_(fr, 256.0f, 0.5f)) * (1.0f / 256.0f);
+    low      = i < 0;
+    i        = i < 0 ? 0 : i;
+    i        = i > n - 1 ? n - 1 : i;
+}
 __device__ __forceinline__ int axis_point(float pn, int n)
 {
     int i = (int)__builtin_floorf(pn * (float)n);
@@ -205,11 +219,21 @@ __device__ __forceinline__ float sample_density01(const SceneDev& S, f3 pos)
     f3    p = to_local(S, pos);
     int   i, j, k;
     float fx, fy, fz;
+    bool  lx = false, ly = false, lz = false;
     if (S.linear)
     {
-        axis_linear(p.x, S.nx, i, fx);
-        axis_linear(p.y, S.ny, j, fy);
-        axis_linear(p.z, S.nz, k, fz);
+        if (QUANT)
+        {
+            axis_linear(p.x, S.nx, i, fx);
+            axis_linear(p.y, S.ny, j, fy);
+            axis_linear(p.z, S.nz, k, fz);
+        }
+        else
+        {
+            axis_linear_f32(p.x, S.nx, i, fx, lx);
+            axis_linear_f32(p.y, S.ny, j, fy, ly);
+            axis_linear_f32(p.z, S.nz, k, fz, lz);
+        }
     }
     else
     {
@@ -229,6 +253,10 @@ __device__ __forceinline__ float sample_density01(const SceneDev& S, f3 pos)
     {
         const float4* q  = reinterpret_cast<const float4*>(S.cells_f32) + idx * 2;
         float4        lo = q[0], hi = q[1];
+        // below the first texel centre of an axis both taps are texel 0 (see axis_linear_f32)
+        if (lx) { lo.y = lo.x; lo.w = lo.z; hi.y = hi.x; hi.w = hi.z; }
+        if (ly) { lo.z = lo.x; lo.w = lo.y; hi.z = hi.x; hi.w = hi.y; }
+        if (lz) hi = lo;
         float x00 = lerpf(lo.x, lo.y, fx);
         float x10 = lerpf(lo.z, lo.w, fx);
         float x01 = lerpf(hi.x, hi.y, fx);

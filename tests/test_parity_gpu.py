@@ -668,3 +668,27 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path):
         assert line["n_gpus"] == n and line["scaling"] == "weak" and line["unit"] == "Msamples/s" and line["value"] > 0
         assert line["config"]["spp_per_step"] == 8 and set(line["roofline"]) >= {"bound", "achieved", "peak", "frac", "traffic"}
     assert np.array_equal(np.load(one), np.load(two))
+
+
+@pytest.mark.parametrize("quantized", [True, False])
+@pytest.mark.parametrize("linear", [True, False])
+def test_density_fetch_pointwise(vp, oracle, quantized, linear):
+    """The tex3D restatement point by point (no integrator around it): random positions in and slightly outside an off-centre,
+    non-cubic box, device fetch == oracle fetch bit for bit.  Float texels below the first texel centre of an axis are the case
+    the randomised scenes of test_fuzz_gpu.py caught: both taps are texel 0 there, but a*(1-w) + a*w is not a in binary32."""
+    import ctypes as C
+    rs = np.random.default_rng(11)
+    g = rs.random((9, 14, 11), dtype=np.float32)
+    g[rs.random(g.shape) < 0.3] = 0
+    grid = np.ascontiguousarray((g * 255).astype(np.uint8)) if quantized else g
+    box = ((-0.7, -1.3, 0.1), (1.6, 0.2, 1.4))
+    osc = oracle.OracleScene(grid, scenes.synthetic_env(), scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, box=box, linear=linear)
+    vp.init_volume(grid, box=box, brick=1, linear=linear)
+    bmin, bmax = np.array(box[0]), np.array(box[1])
+    pts = (bmin + (bmax - bmin) * rs.uniform(-0.08, 1.08, (6000, 3))).astype(np.float32)
+    pts[:64] = (bmin + (bmax - bmin) * rs.integers(0, 2, (64, 3))).astype(np.float32)      # the corners themselves
+    got = vp.test_sample_density(pts)
+    L = oracle.lib()
+    ref = np.array([L.vpo_sample_density(C.byref(osc.S), (C.c_float * 3)(*p)) for p in pts], np.float32)
+    bad = np.flatnonzero(got != ref)
+    assert len(bad) == 0, (len(bad), pts[bad[0]], got[bad[0]], ref[bad[0]])
