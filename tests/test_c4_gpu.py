@@ -293,3 +293,37 @@ def test_tuning_knobs_are_validated_and_never_change_results(tmp_path):
         if name == "bad":
             assert r.stderr.count("ignoring VP_") == 4, r.stderr
     assert len(set(hashes.values())) == 1, hashes
+
+
+def test_full_size_tables_do_not_change_a_bit_for_any_camera():
+    """The per-pixel tables, the pixel classes and the light kernel at BASELINE size (256^3, 800x600) for cameras the
+    hand-picked tests never use: inside the volume, close to a face, far away and off-axis.  Same process state, same
+    frames, the optimisations switched off by their knobs in a second process: identical accumulators (hash) for the
+    global-majorant and the decomposition estimator, the latter across the frame-11 switch."""
+    import sys
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, volpath as vp\n"
+        "from volpath import scene, host\n"
+        "vp.set_device(0); out = []\n"
+        "cams = [((0.05, 0.1, -0.02), (0.3, -0.2, 0.93), (0, 1, 0)), ((1.02, 0.4, 0.3), (-1, -0.3, -0.2), (0, 0, 1)),\n"
+        "        ((-7.0, 5.0, 3.0), (0.75, -0.55, -0.36), (0, 1, 0)), ((0.3, 0.2, 2.5), (0.0, 0.0, -1.0), (1, 0, 0))]\n"
+        "for wl, first, n in (('c2', 0, 3), ('c3ref', 9, 4)):\n"
+        "    P, info = scene.setup(wl, rng_mode=vp.RNG_PHILOX7, last_frame=first + n)\n"
+        "    for pos, fwd, up in cams:\n"
+        "        f = np.array(fwd, np.float32); f /= np.linalg.norm(f)\n"
+        "        u = np.cross(np.cross(f, np.array(up, np.float32)), f); u /= np.linalg.norm(u)\n"
+        "        vp.set_camera(host.camera_matrix(np.array(pos, np.float32), f, u.astype(np.float32)))\n"
+        "        b = vp.DeviceBuffer(P.width, P.height); vp.render_frames(b.ptr, first, n, P)\n"
+        "        a = b.download(); out.append(hashlib.sha1(a.tobytes()).hexdigest()[:16] + ':%%.4g' %% float(a[..., :3].mean())); b.free()\n"
+        "print('HASH', *out)\n"
+    ) % (os.path.join(ROOT, "cuda-volpath_amd"), os.path.join(ROOT, "tests"))
+    res = {}
+    for name, env in (("default", {}), ("plain", {"VP_NO_CRAWL_TABLE": "1", "VP_NO_EMPTY_TABLE": "1", "VP_NO_LIGHT": "1"})):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[name] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0].split()[1:]
+    assert res["default"] == res["plain"], res
+    assert len(set(res["default"])) == 8          # eight different images ...
+    assert all(float(h.split(":")[1]) > 0 for h in res["default"])     # ... none of them black
