@@ -768,7 +768,11 @@ void render_k(SceneDev S, LaunchDev L)
             unsigned long long wm = __ballot(!active && !(st == ST_DONE && exhausted));
             unsigned nwait = (unsigned)__popcll(wm);
             if (am == 0ull || nwait >= L.wait_lanes || (nwait > 0u && iter >= (int)L.wait_iters)) break;
-            if (COUNT && lane == 0) { d_iter++; d_act += (unsigned)__popcll(am); d_shadow += (unsigned)__popcll(__ballot(st == ST_SHADOW)); }
+            if (COUNT)
+            {
+                const unsigned long long sm = __ballot(st == ST_SHADOW);   // (a ballot under `lane == 0` would see lane 0 only)
+                if (lane == 0) { d_iter++; d_act += (unsigned)__popcll(am); d_shadow += (unsigned)__popcll(sm); }
+            }
             if (!active) continue;
             segment_setup();
             tracking_step();
@@ -778,7 +782,8 @@ void render_k(SceneDev S, LaunchDev L)
                 if (COUNT)
                 {
                     unsigned long long am2 = __ballot((st == ST_TRACK) || (st == ST_SHADOW) || (LOCAL && st == ST_SETUP));
-                    if (lane == 0) { d_iter++; d_act += (unsigned)__popcll(am2); d_shadow += (unsigned)__popcll(__ballot(st == ST_SHADOW)); }
+                    const unsigned long long sm2 = __ballot(st == ST_SHADOW);
+                    if (lane == 0) { d_iter++; d_act += (unsigned)__popcll(am2); d_shadow += (unsigned)__popcll(sm2); }
                 }
                 // a restart segment is set up at once while many lanes ask for one (the crawl toward and through empty bricks,
                 // quirk Q6); a few stragglers -- a dense region ends a 0.05 segment every ~40 steps per lane -- wait for the

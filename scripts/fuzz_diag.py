@@ -21,18 +21,19 @@ if "achromatic" in ov: c["kw"].pop("sigma_t", None); c["kw"].pop("albedo", None)
 if "defcam" in ov: c["cam"] = np.array(vp.DEFAULT_CAMERA, np.float32)
 if "defbox" in ov: c["box"] = None
 c["late"] = c["late"] and c["est"] == 1
+c["env_mis"] = bool(int(ov.get("env_mis", 0))); c["track"] = int(ov.get("track", 0))
 ref, cnt = T._oracle_render(oracle, c)
 vp.set_device(0)
 vP = vp.make_param(c["W"], c["H"], **c["kw"])
 vp.init_volume(c["grid"], box=c["box"], brick=c["brick"], linear=c["linear"]); vp.init_envmap(c["env"]); vp.set_sun(c["sun_dir"], c["sun_power"])
-vp.set_camera(c["cam"]); vp.set_estimator(c["est"]); vp.set_rng(c["rng_mode"], c["key"]); vp.set_shard(0, 1)
+vp.set_tracking(c["track"]); vp.set_envmap_sampling(1 if c["env_mis"] else 0); vp.set_camera(c["cam"]); vp.set_estimator(c["est"]); vp.set_rng(c["rng_mode"], c["key"]); vp.set_shard(0, 1)
 if c["late"]: vp.precompute_opacity(c["sun_dir"])
 buf = vp.DeviceBuffer(c["W"], c["H"])
 vp.render_frames(buf.ptr, c["first"], c["nframes"], vP)
 got = buf.download()
 bad = np.argwhere(np.any(got != ref, axis=-1))
 print(f"seed {seed} {ov}: grid {c['grid'].shape} {c['grid'].dtype} est {c['est']} rng {c['rng_mode']} linear {c['linear']} brick {c['brick']} box {c['box'] is not None} "
-      f"{c['W']}x{c['H']} frames {c['first']}+{c['nframes']}: {len(bad)} differing pixels of {c['W'] * c['H']}, max abs {np.abs(got - ref).max():.3g}; sca/smp {cnt['scatters'] / cnt['samples']:.2f}")
+      f"{c['W']}x{c['H']} frames {c['first']}+{c['nframes']}: {len(bad)} differing of {c['W'] * c['H']}, max abs {np.abs(got - ref).max():.3g}; sca/smp {cnt['scatters'] / cnt['samples']:.2f}")
 for y, x in bad[:4]:
     print("   pixel", (x, y), "got", got[y, x], "ref", ref[y, x])
 # component check: the density fetch at random points of the box (and a little outside)
