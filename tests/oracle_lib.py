@@ -8,6 +8,13 @@ import subprocess
 
 import numpy as np
 
+# OpenMP's own default is one thread per logical CPU of the HOST; a container that may use 8 or 16 of them spends its time
+# switching between 200 threads.  The CPUs this process may run on, at most 16.
+try:
+    DEFAULT_THREADS = max(1, min(16, len(os.sched_getaffinity(0))))
+except AttributeError:
+    DEFAULT_THREADS = max(1, min(16, os.cpu_count() or 1))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 _LIB = None
@@ -176,6 +183,7 @@ class OracleScene:
         self.pdfnorm_alt = norm.value
 
     def precompute_opacity(self, threads=0):
+        threads = threads or DEFAULT_THREADS
         S = self.S
         self.opacity = np.empty((S.nz, S.ny, S.nx), np.float32)
         lib().vpo_precompute_opacity(C.byref(S), S.sun_dir, _p(self.opacity), threads)
@@ -183,6 +191,7 @@ class OracleScene:
         return self.opacity
 
     def render_frame(self, P, frame, accum=None, rows=None, threads=0):
+        threads = threads or DEFAULT_THREADS
         if accum is None:
             accum = np.zeros((P.height, P.width, 4), np.float32)
         y0, y1 = rows if rows else (0, P.height)

@@ -168,3 +168,100 @@ def test_random_scene_bit_exact(vp, oracle, seed):
         vp.set_envmap_sampling(0)
         vp.set_camera()
         buf.free()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_call_sequences(vp, oracle, seed):
+    """The reference's entry points in random order: render_kernel for consecutive, repeated and far-away frames (the frame
+    look-ahead stages consecutive ones in batches), batched vp_render_frames, and between them every setter a host may call --
+    Param, camera, estimator, stream, sun, environment, look-ahead depth, accumulator.  Whatever is staged must be dropped when
+    it no longer applies: after every call sequence the accumulators equal the oracle's, rendered call by call."""
+    from volpath import host
+    rng = np.random.default_rng(7000 + seed)
+    W, H = 40, 24
+    grid = oracle.julia(16) if seed % 2 == 0 else scenes.blob_volume_u8(14, seed=seed)
+    st = dict(est=int(rng.integers(0, 3)), rng_mode=int(rng.integers(0, 3)), key=(int(rng.integers(0, 1 << 30)), 5), density=200.0, g=0.6,
+              cam=None, sun=scenes.DEFAULT_SUN_DIR, env_seed=3)
+
+    def make_oracle():
+        env = scenes.synthetic_env(seed=st["env_seed"])
+        o = oracle.OracleScene(grid, env, st["sun"], scenes.DEFAULT_SUN_POWER, brick=1, estimator=st["est"], rng_mode=st["rng_mode"], seed=st["key"],
+                               inv_view=st["cam"])
+        if st["est"] == 1:
+            o.precompute_opacity()
+        return o
+
+    def apply_all():
+        vp.init_volume(grid, brick=1)
+        vp.init_envmap(scenes.synthetic_env(seed=st["env_seed"]))
+        vp.set_sun(st["sun"], scenes.DEFAULT_SUN_POWER)
+        vp.set_camera() if st["cam"] is None else vp.set_camera(st["cam"])
+        vp.set_estimator(st["est"]); vp.set_rng(st["rng_mode"], st["key"]); vp.set_shard(0, 1)
+        vp.set_tracking(0); vp.set_envmap_sampling(0)
+        if st["est"] == 1:
+            vp.precompute_opacity(st["sun"])
+
+    apply_all()
+    osc = make_oracle()
+    bufs = [vp.DeviceBuffer(W, H), vp.DeviceBuffer(W, H)]
+    refs = [np.zeros((H, W, 4), np.float32), np.zeros((H, W, 4), np.float32)]
+    cur, frame, log = 0, 0, []
+    try:
+        for step in range(110):
+            u = rng.random()
+            P_o = oracle.default_param(W, H, density=st["density"], g=st["g"])
+            P_v = vp.make_param(W, H, density=st["density"], g=st["g"])
+            if u < 0.60:
+                frame += 1
+                vp.render_kernel(bufs[cur].ptr, frame, P_v); refs[cur], _ = osc.render_frame(P_o, frame, refs[cur]); log.append(("k", frame))
+            elif u < 0.64:
+                vp.render_kernel(bufs[cur].ptr, frame, P_v); refs[cur], _ = osc.render_frame(P_o, frame, refs[cur]); log.append(("again", frame))
+            elif u < 0.68:
+                frame = int(rng.integers(0, 5000))
+                vp.render_kernel(bufs[cur].ptr, frame, P_v); refs[cur], _ = osc.render_frame(P_o, frame, refs[cur]); log.append(("jump", frame))
+            elif u < 0.74:
+                n = int(rng.integers(1, 6))
+                vp.render_frames(bufs[cur].ptr, frame + 1, n, P_v)
+                for f in range(frame + 1, frame + 1 + n):
+                    refs[cur], _ = osc.render_frame(P_o, f, refs[cur])
+                frame += n; log.append(("batch", n))
+            elif u < 0.79:
+                st["density"] = float(np.float32(rng.uniform(20, 900))); st["g"] = float(np.float32(rng.uniform(-0.5, 0.9))); log.append("param")
+            elif u < 0.83:
+                d = rng.normal(size=3); d /= np.linalg.norm(d)
+                pos = (d * rng.uniform(0.4, 4.0)).astype(np.float32)
+                fwd = (-d + 0.2 * rng.normal(size=3)); fwd /= np.linalg.norm(fwd)
+                up = np.cross(fwd, rng.normal(size=3)); up /= np.linalg.norm(up)
+                st["cam"] = host.camera_matrix(pos, fwd.astype(np.float32), up.astype(np.float32))
+                vp.set_camera(st["cam"]); osc = make_oracle(); log.append("camera")
+            elif u < 0.86:
+                st["est"] = int(rng.integers(0, 3)); vp.set_estimator(st["est"])
+                if st["est"] == 1:
+                    vp.precompute_opacity(st["sun"])
+                osc = make_oracle(); log.append(("est", st["est"]))
+            elif u < 0.89:
+                st["rng_mode"] = int(rng.integers(0, 3)); st["key"] = (int(rng.integers(0, 1 << 30)), int(rng.integers(0, 99)))
+                vp.set_rng(st["rng_mode"], st["key"]); osc = make_oracle(); log.append(("rng", st["rng_mode"]))
+            elif u < 0.91:
+                s3 = rng.normal(size=3); s3 /= np.linalg.norm(s3)
+                st["sun"] = tuple(float(np.float32(v)) for v in s3)
+                vp.set_sun(st["sun"], scenes.DEFAULT_SUN_POWER)
+                if st["est"] == 1:
+                    vp.precompute_opacity(st["sun"])
+                osc = make_oracle(); log.append("sun")
+            elif u < 0.93:
+                st["env_seed"] = int(rng.integers(0, 100)); vp.init_envmap(scenes.synthetic_env(seed=st["env_seed"])); osc = make_oracle(); log.append("env")
+            elif u < 0.96:
+                vp.set_lookahead(int(rng.choice([0, 2, 8, 64]))); log.append("lookahead")
+            else:
+                cur = 1 - cur; log.append("buffer")
+            if step % 23 == 22:
+                for b, r in zip(bufs, refs):
+                    assert np.array_equal(b.download(), r, equal_nan=True), (seed, step, log[-12:])
+        for b, r in zip(bufs, refs):
+            assert np.array_equal(b.download(), r, equal_nan=True), (seed, "end", log[-12:])
+    finally:
+        vp.set_lookahead(64)
+        vp.set_camera()
+        for b in bufs:
+            b.free()
