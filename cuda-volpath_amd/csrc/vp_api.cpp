@@ -714,7 +714,9 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             // what fits a SIMD's 512 vector registers side by side: global majorant 4 x 80 (achromatic; 88 otherwise) + 3 (2) x 64,
             // local majorant 5 x 96 + ... the light kernel's blocks take what is left as general blocks retire
             const bool ach = p->sigma_t.x == p->sigma_t.y && p->sigma_t.y == p->sigma_t.z && p->albedo.x == p->albedo.y && p->albedo.y == p->albedo.z;
-            if (both && cls) bpc = G.light_blocks_per_cu ? G.light_blocks_per_cu : (G.est == VP_EST_GLOBAL ? (ach ? 3u : 2u) : 2u);
+            // (local majorant, five 96-register general waves per SIMD: the light kernel's workgroups find room as general ones retire,
+            // i.e. mostly at the end -- then as many of them as fit)
+            if (both && cls) bpc = G.light_blocks_per_cu ? G.light_blocks_per_cu : (G.est == VP_EST_GLOBAL ? (ach ? 3u : 2u) : 6u);
             if (both && !cls) bpc = G.general_blocks_per_cu ? G.general_blocks_per_cu : (G.est == VP_EST_GLOBAL ? 4u : 5u);
             unsigned cap    = (unsigned)G.num_cu * (ldsb ? 2u : bpc);
             if (blocks > cap) blocks = cap;
