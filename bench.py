@@ -159,6 +159,15 @@ def main():
         vp.enable_counters(False)
         bytes_per_sample = algorithmic_bytes_per_sample(counters)
         fetched_bytes_per_sample = algorithmic_bytes_per_sample(counters, loads=True)
+        # where the samples go: the pixel classes of this camera -- general pixels are tracked by the general
+        # kernel, "light" ones (the camera ray meets certified-empty cells only) by the light kernel, and a ray that misses
+        # the box is one environment lookup, evaluated once per pixel and written for every frame
+        try:
+            import numpy as np
+            cls = np.bincount(vp.pixel_table(P)[..., 5].astype(int).ravel(), minlength=3)
+            pixel_classes = {"general": float(cls[0]) / cls.sum(), "light": float(cls[1]) / cls.sum(), "misses_box": float(cls[2]) / cls.sum()}
+        except Exception:
+            pixel_classes = None      # no pixel table in this configuration (tables switched off)
 
         def step(i):
             acc.zero_()
@@ -244,6 +253,7 @@ def main():
                          "fetched_bytes_per_sample": fetched_bytes_per_sample,
                          "fetched_GBps": fetched_bytes_per_sample * samples_rank / launches / (launch_ms * 1e-3) / 1e9,
                          "reference_estimator_bytes_per_sample": REFERENCE_ESTIMATOR_BYTES_PER_SAMPLE,
+                         "pixel_classes": pixel_classes,
                          "lookups_per_sample": {k: counters[k] / max(counters["samples"], 1) for k in
                                                 ("density_lookups", "density_loads", "bound_lookups", "opacity_lookups", "env_lookups", "scatters")}},
         }
