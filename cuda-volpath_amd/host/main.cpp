@@ -25,7 +25,8 @@ static void usage()
            "               [--tracking spectral|scalar|multichannel] [--env passive|mis]\n"
            "               [--sun X Y] [--batch F] [--out name(.ppm|.hdr)]\n"
            "               [--gpus N [--devices a,b,...]]   N contexts, pixel tiles dealt by vp_set_shard, one RCCL reduce;\n"
-           "                                                a repeated device (e.g. --gpus 2 --devices 0,0) shares one GPU\n");
+           "                                                a repeated device (e.g. --gpus 2 --devices 0,0) shares one GPU\n"
+           "               [--rccl-selftest [device]]       load RCCL, one-rank communicator, one reduce: the calls of the N > 1 path\n");
 }
 
 int main(int argc, char** argv)
@@ -68,6 +69,15 @@ int main(int argc, char** argv)
         else if (a == "--out") { need(1); out = argv[++i]; }
         else if (a == "--gpus") { need(1); gpus = atoi(argv[++i]); }
         else if (a == "--devices") { need(1); devlist = argv[++i]; }
+        else if (a == "--rccl-selftest")
+        {
+            // the RCCL calls of the multi-GPU path on one device (multigpu.h)
+            const int   dev = i + 1 < argc ? atoi(argv[i + 1]) : 0;
+            std::string report;
+            const bool  ok = volpath::rccl_selftest(dev, (size_t)1280 * 720 * 4, report);
+            printf("%s\n", report.c_str());
+            return ok ? 0 : 1;
+        }
         else { usage(); return a == "--help" ? 0 : 2; }
     }
 

@@ -32,20 +32,64 @@ bool sym(void* lib, const char* name, F& f)
 }
 }  // namespace
 
+static bool load_rccl(void*& lib, std::string& err)
+{
+    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { err = std::string("cannot load librccl.so.1: ") + dlerror(); return false; }
+    if (!sym(lib, "ncclCommInitAll", R.CommInitAll) || !sym(lib, "ncclCommDestroy", R.CommDestroy) || !sym(lib, "ncclReduce", R.Reduce) ||
+        !sym(lib, "ncclGroupStart", R.GroupStart) || !sym(lib, "ncclGroupEnd", R.GroupEnd) || !sym(lib, "ncclGetErrorString", R.GetErrorString))
+    {
+        err = "librccl.so.1 lacks an expected symbol";
+        return false;
+    }
+    return true;
+}
+
+bool rccl_selftest(int device, size_t count, std::string& report)
+{
+    void* lib = nullptr;
+    if (!load_rccl(lib, report)) return false;
+    bool        ok = false;
+    ncclComm_t  comm = nullptr;
+    float*      d = nullptr;
+    hipStream_t st = nullptr;
+    std::vector<float> h(count), back(count);
+    for (size_t i = 0; i < count; i++) h[i] = (float)(i % 1000) * 0.25f - 7.0f;
+    do
+    {
+        if (hipSetDevice(device) != hipSuccess) { report = "hipSetDevice failed"; break; }
+        ncclResult_t rc = R.CommInitAll(&comm, 1, &device);
+        if (rc != ncclSuccess) { report = std::string("ncclCommInitAll: ") + R.GetErrorString(rc); comm = nullptr; break; }
+        if (hipStreamCreate(&st) != hipSuccess || hipMalloc((void**)&d, count * sizeof(float)) != hipSuccess) { report = "hipMalloc / hipStreamCreate failed"; break; }
+        if (hipMemcpyAsync(d, h.data(), count * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) { report = "upload failed"; break; }
+        rc = R.GroupStart();
+        if (rc == ncclSuccess) rc = R.Reduce(d, d, count, ncclFloat, ncclSum, 0, comm, st);
+        ncclResult_t rc2 = R.GroupEnd();
+        if (rc == ncclSuccess) rc = rc2;
+        if (rc != ncclSuccess) { report = std::string("ncclReduce: ") + R.GetErrorString(rc); break; }
+        if (hipMemcpyAsync(back.data(), d, count * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        {
+            report = "download failed";
+            break;
+        }
+        ok = back == h;   // the sum over one rank is the rank's own data
+        report = ok ? "ncclCommInitAll(1 rank) + ncclReduce(sum, float, " + std::to_string(count) + ") on device " + std::to_string(device) + ": ok"
+                    : "ncclReduce over one rank changed the data";
+    } while (false);
+    if (d) (void)hipFree(d);
+    if (st) (void)hipStreamDestroy(st);
+    if (comm) R.CommDestroy(comm);
+    dlclose(lib);
+    return ok;
+}
+
 bool NodeReducer::init(const std::vector<int>& devices, std::string& err)
 {
     devices_ = devices;
     std::set<int> distinct(devices.begin(), devices.end());
     if (devices.size() < 2 || distinct.size() != devices.size()) return true;  // one GPU, or contexts sharing a GPU: no collective
-    lib_ = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!lib_) lib_ = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!lib_) { err = std::string("cannot load librccl.so.1: ") + dlerror(); return false; }
-    if (!sym(lib_, "ncclCommInitAll", R.CommInitAll) || !sym(lib_, "ncclCommDestroy", R.CommDestroy) || !sym(lib_, "ncclReduce", R.Reduce) ||
-        !sym(lib_, "ncclGroupStart", R.GroupStart) || !sym(lib_, "ncclGroupEnd", R.GroupEnd) || !sym(lib_, "ncclGetErrorString", R.GetErrorString))
-    {
-        err = "librccl.so.1 lacks an expected symbol";
-        return false;
-    }
+    if (!load_rccl(lib_, err)) return false;
     std::vector<ncclComm_t> comms(devices.size());
     ncclResult_t rc = R.CommInitAll(comms.data(), (int)devices.size(), devices.data());
     if (rc != ncclSuccess) { err = std::string("ncclCommInitAll: ") + R.GetErrorString(rc); return false; }

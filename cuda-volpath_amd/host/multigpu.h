@@ -13,6 +13,12 @@
 
 namespace volpath
 {
+// The RCCL call sequence of NodeReducer on ONE device: load librccl.so.1, ncclCommInitAll for a single rank, one in-place
+// ncclReduce(sum) of `count` floats on a stream of that device, compare, destroy.  It cannot show that ranks talk to each other --
+// a one-GPU box has nobody to talk to -- but it does run every RCCL entry point this host uses on the hardware.
+// (`volpath_render --rccl-selftest [device]`)
+bool rccl_selftest(int device, size_t count, std::string& report);
+
 class NodeReducer
 {
 public:

@@ -327,3 +327,37 @@ def test_full_size_tables_do_not_change_a_bit_for_any_camera():
     assert res["default"] == res["plain"], res
     assert len(set(res["default"])) == 8          # eight different images ...
     assert all(float(h.split(":")[1]) > 0 for h in res["default"])     # ... none of them black
+
+
+def test_rccl_calls_of_the_multi_gpu_host_run_on_this_gpu():
+    """The one-GPU box cannot run a collective between ranks, but it can run the calls: `volpath_render --rccl-selftest` loads
+    librccl.so.1 (dlopen, as the N > 1 path does), creates a one-rank communicator with ncclCommInitAll and runs one
+    ncclReduce(sum, float, 1280x720x4) in place on a stream; the sum over one rank is the rank's own data."""
+    exe = os.path.join(ROOT, "cuda-volpath_amd", "volpath_render")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([exe, "--rccl-selftest", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ncclReduce(sum, float, 3686400) on device 0: ok" in r.stdout, r.stdout
+
+
+def test_torch_rccl_backend_runs_a_one_rank_reduce():
+    """bench.py --gpus N sums the ranks' accumulators with torch.distributed over backend "nccl" (= RCCL on ROCm).  With one
+    GPU the collective has one rank, but process-group creation, the communicator and a reduce on a side stream -- the calls of
+    bench.py's N > 1 branch -- do run here."""
+    import sys
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(dev)\n"
+        "dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=dev)\n"
+        "s = torch.cuda.Stream(device=dev)\n"
+        "with torch.cuda.stream(s):\n"
+        "    a = torch.arange(1280 * 720 * 4, device=dev, dtype=torch.float32).reshape(720, 1280, 4) * 0.5\n"
+        "    b = a.clone(); dist.reduce(a, dst=0, op=dist.ReduceOp.SUM)\n"
+        "s.synchronize(); dist.barrier(); ok = bool(torch.equal(a, b)); dist.destroy_process_group(); print('REDUCE', ok)\n"
+    )
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "REDUCE True" in r.stdout, r.stdout + r.stderr
