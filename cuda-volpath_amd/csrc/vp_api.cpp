@@ -977,7 +977,7 @@ void gamma_correct(vp_float4* dst, vp_float4* src, int size, float s, float gamm
 
 // =============================================================================== Part 2
 const char* vp_last_error(void) { return G.err.c_str(); }
-const char* vp_version(void) { return "volpath_hip 0.1 (gfx950)"; }
+const char* vp_version(void) { return "volpath_hip 0.2 (gfx950)"; }
 int vp_device_count(void)
 {
     int n = 0;
