@@ -2,17 +2,23 @@
 """bench.py -- Msamples/s of the volumetric radiance integrator on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one complete render job of the Julia-256^3 scene at 800x600: `spp` samples per pixel,
-pixel tiles dealt over the ranks (vp_tile_owner), followed (N > 1) by one RCCL reduce of the HDR
-accumulators to rank 0.  spp = 1024 * N, so every GPU always integrates 800*600*1024 samples per
-step ("weak" scaling); at N = 1 this is BASELINE.json's configs[1] exactly.  Inputs are resident
-in HBM before the timed region.  Prints ONE JSON line on rank 0.
+runs as typed for any N: with N > 1 and no WORLD_SIZE in the environment it starts
+`python -m torch.distributed.run --standalone --nproc-per-node N bench.py ...` as a CHILD process (before anything
+touches the GPU) and relays its JSON line and exit code; under an external torch.distributed.run it is one rank.
+
+A step = one complete render job of the Julia-256^3 scene at 800x600: `spp` samples per pixel, pixel tiles dealt over
+the ranks (vp_tile_owner), followed (N > 1) by one RCCL reduce of the HDR accumulators to rank 0.  --scaling weak
+(default): spp = 1024 * N, every GPU integrates 800*600*1024 samples per step; at N = 1 this is BASELINE.json's
+configs[1] exactly.  --scaling strong: spp = 1024 whatever N (the job is fixed, the ranks share it); --scaling both
+prints the weak line with the strong measurement inside it ("strong").  Inputs are resident in HBM before the timed
+region.  Prints ONE JSON line on rank 0; at N = 1 it also carries the reference's live estimator on the same scene
+(BASELINE configs[2], "secondary") and the CPU baseline.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,13 +33,15 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
 # bound + 1.0 environment lookups): 8*97.6 + 2*51.3 + 16*1.0 + 32.  Quoted next to this build's own figure so that a
 # workload that does more (C2's global majorant: ~525 lookups) or less work per sample is not mis-read as bandwidth.
 REFERENCE_ESTIMATOR_BYTES_PER_SAMPLE = 8 * 97.6 + 2 * 51.3 + 16 * 1.0 + 32
+WORKLOAD_CHOICES = ["c2", "c3", "c3ref", "c1", "c4s", "c4f"]
 
 
-def algorithmic_bytes_per_sample(c, loads=False):
+def bytes_per_sample(c, loads):
     """8*L_d + 2*L_b + 32*L_o + 16*L_e + 32 (accumulator read+write).
-    L_d = trilinear density lookups the estimator asks for (the oracle counts the same number); with loads=True the lookups
-    that really issued a load: free-flight steps of a camera ray through certified-empty cells use the +0 such a fetch
-    returns without fetching."""
+    loads=True: L_d = the density lookups that ISSUED A LOAD in the timed kernels (the build's own counter: free-flight steps of
+    a camera ray through certified-empty cells, and of a sun shadow ray that has only empty cells left, use the +0 such a fetch
+    returns without fetching -- DESIGN.md section 5).  loads=False: every lookup the estimator asks for (the oracle counts the
+    same number): what a build without those certificates would load."""
     n = max(c["samples"], 1)
     ld = c["density_loads"] if loads else c["density_lookups"]
     return (8.0 * ld + 2.0 * c["bound_lookups"] + 32.0 * c["opacity_lookups"] + 16.0 * c["env_lookups"]) / n + 32.0
@@ -51,18 +59,18 @@ def effective_cores():
     return max(1, n)
 
 
-def cpu_baseline(workload, seconds_hint=20.0):
+def cpu_baseline(workload, seconds_hint=15.0):
     """The oracle (CPU restatement, 'port') on this host's cores, on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
     import oracle_lib as O
     from volpath import scene as vscene
     cfg = vscene.WORKLOADS[workload]
     O.build()
-    grid = O.julia(cfg["n"])
+    grid = vscene.host_volume(workload, oracle=O)
     env, sun_dir, sun_power = vscene.default_sunsky()
     osc = O.OracleScene(grid, env, sun_dir, sun_power,
-                        brick=cfg["brick"], estimator=cfg["est"], rng_mode=O.RNG_PHILOX7, seed=(0x9E3779B9, 0x85EBCA6B))
+                        brick=cfg["brick"], estimator=cfg["est"], rng_mode=O.RNG_PHILOX7, seed=(0x9E3779B9, 0x85EBCA6B),
+                        inv_view=vscene.camera_of(cfg))
     P = O.default_param(cfg["width"], cfg["height"])
     if cfg["chromatic"]:
         O.mat(P, *vscene.PRESET1)
@@ -75,12 +83,11 @@ def cpu_baseline(workload, seconds_hint=20.0):
         osc.precompute_opacity()
     max_frames = 16 if (cfg["est"] != O.EST_DECOMP or across_q5) else 11
     nframes, acc, tot, t0 = 0, None, 0, time.time()
-    budget = seconds_hint
     while True:
         acc, c = osc.render_frame(P, nframes, acc, threads=cores)
         tot += c.samples
         nframes += 1
-        if time.time() - t0 > budget or nframes >= max_frames:
+        if time.time() - t0 > seconds_hint or nframes >= max_frames:
             break
     dt = time.time() - t0
     return {"value": tot / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
@@ -90,21 +97,213 @@ def cpu_baseline(workload, seconds_hint=20.0):
                          if cfg["est"] == O.EST_DECOMP and not across_q5 else ")")}
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` typed by hand (no WORLD_SIZE): start the ranks as a child torchrun.  Nothing in this process
+    has touched the GPU yet, and it never will: it relays the child's output and exit code."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.run(cmd, env=env)
+    raise SystemExit(p.returncode)
+
+
+def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=True):
+    """Time `steps` render jobs of one workload; returns the fields of the JSON line (rank 0) or None."""
+    import torch
+    import torch.distributed as dist
+    import volpath as vp
+    from volpath import scene as vscene
+    rank, world, dev, stream, rehearsal = ctx["rank"], ctx["world"], ctx["dev"], ctx["stream"], ctx["rehearsal"]
+    spp_step = spp_per_gpu * world if scaling == "weak" else spp_per_gpu
+    total_steps = warmup + steps
+    rng_mode = {"philox": vp.RNG_PHILOX, "philox7": vp.RNG_PHILOX7, "samplerh": vp.RNG_SAMPLERH}[args.rng]
+    count_frames = 4 if vscene.WORKLOADS[workload]["est"] == vp.EST_GLOBAL else 16  # frames of the (untimed) work-counter pass
+    P, info = vscene.setup(workload, rng_mode=rng_mode, rank=rank, world=world,
+                           last_frame=max(spp_step * total_steps, count_frames), sunsky=ctx.setdefault("sunsky", None))
+    ctx["sunsky"] = info["sunsky"]
+    W, H = P.width, P.height
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        acc = torch.zeros(H, W, 4, device=dev, dtype=torch.float32)
+        image = torch.zeros(H, W, 4, device=dev, dtype=torch.float32) if rank == 0 else None
+
+        # per-camera set-up at full size (untimed region, reported): the per-pixel tables of the camera, the class split and
+        # the pixel lists (GPU kernels + one 12-byte read-back), the sun table.  Forced by moving the camera away and back.
+        cam = info["camera"]
+        moved = list(cam)
+        moved[3] += 0.01
+        vp.set_camera(moved)
+        vp.prepare(P)
+        vp.set_camera(cam)
+        vp.synchronize()
+        t0 = time.perf_counter()
+        vp.prepare(P)
+        per_camera_setup_ms = (time.perf_counter() - t0) * 1e3
+
+        # work counters (untimed, counting kernel variant): per-sample lookups of THIS build
+        vp.enable_counters(True)
+        vp.read_counters(reset=True)
+        vp.render_frames(acc.data_ptr(), 0, count_frames, P)
+        counters = vp.read_counters(reset=True)
+        vp.enable_counters(False)
+
+        def step(i):
+            acc.zero_()
+            vp.render_frames(acc.data_ptr(), i * spp_step, spp_step, P)
+            if world > 1 and rehearsal:
+                host = acc.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                acc.copy_(host)
+            elif world > 1:
+                dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI
+            if rank == 0:
+                image.add_(acc)
+
+        for i in range(warmup):
+            step(i)
+        barrier()
+        vp.render_time_ms(reset=True)
+        vp.render_class_time_ms(reset=True)
+        t0 = time.perf_counter()
+        for i in range(warmup, total_steps):
+            step(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        kern_ms, launches = vp.render_time_ms(reset=True)
+        class_ms, class_px = vp.render_class_time_ms(reset=True)
+
+    kern_ms, launches = max(kern_ms, 1e-9), max(launches, 1)
+    # per-rank diagnostics: wall time of the timed region and kernel time of each rank (rank order), so that an N > 1 line
+    # shows whether the tile deal balanced the work
+    t = torch.tensor([dt, kern_ms], device=torch.device("cpu") if rehearsal else dev, dtype=torch.float64)
+    per_rank = [t.clone() for _ in range(world)] if world > 1 else [t]
+    if world > 1:
+        dist.all_gather(per_rank, t)
+    walls = [float(x[0]) for x in per_rank]
+    kerns = [float(x[1]) for x in per_rank]
+    dt = max(walls)
+    if rank != 0:
+        return None
+
+    samples_total = float(W) * H * spp_step * steps                 # all ranks together
+    frames_rank = spp_step * steps                                  # frames this rank rendered (of its own tiles)
+    pixels_rank = sum(class_px.values())
+    samples_rank = float(pixels_rank) * frames_rank
+    value = samples_total / dt / 1e6
+    launch_ms = kern_ms / launches
+    n_cnt = max(counters["samples"], 1)
+    loaded_bps = bytes_per_sample(counters, loads=True)
+    estimator_bps = bytes_per_sample(counters, loads=False)
+    achieved = loaded_bps * samples_rank / launches / (launch_ms * 1e-3) / 1e9
+    # per pixel class: which kernel integrates how many samples at what rate (the general and the light kernel run side by
+    # side, so their times overlap; each is measured with its own pair of HIP events)
+    per_class = {}
+    for name in ("general", "light", "misses_box"):
+        px, ms = class_px[name], class_ms[name]
+        smp = float(px) * frames_rank
+        per_class[name] = {"pixels": px, "pixel_fraction": px / max(pixels_rank, 1), "samples": smp, "kernel_ms": ms,
+                           "kernel_ms_per_launch": ms / launches, "msamples_per_s": (smp / (ms * 1e-3) / 1e6) if ms > 0 else None}
+    # the density lookups of the light and box-missing classes issue no load; every load belongs to the general kernel
+    gen = per_class["general"]
+    if gen["kernel_ms"] > 0:
+        lookups_general = counters["density_lookups"] / n_cnt * samples_rank
+        # (estimator lookups of the general pixels are not counted separately; loads are all theirs)
+        gen["density_loads_per_s"] = counters["density_loads"] / n_cnt * samples_rank / (gen["kernel_ms"] * 1e-3)
+        gen["density_loads_per_sample"] = counters["density_loads"] / n_cnt * samples_rank / max(gen["samples"], 1.0)
+        per_class["all"] = {"density_lookups_per_s": lookups_general / (kern_ms * 1e-3)}
+    out = {
+        "metric": "Msamples/sec (WxHxspp) + achieved HBM GB/s, Julia 256^3 @ 800x600",
+        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": info["name"], "volume": info.get("volume", f"{info['n']}^3 uchar Julia set"), "image": f"{W}x{H}",
+                   "spp_per_step": spp_step, "samples_per_step": int(W * H * spp_step),
+                   "estimator": "global_majorant" if info["est"] == vp.EST_GLOBAL else "decomposition",
+                   "bound_brick": info["brick"],
+                   "rng": {"philox": "philox2x32-10", "philox7": "philox2x32-7", "samplerh": "sampler.h"}[args.rng],
+                   "parallelism": f"pixel-tiles x{world}" + (" + RCCL reduce" if world > 1 else ""),
+                   "sky": "Hosek sun/sky bake, setup_sunsky(0.5, 0.2), 1024x512"},
+        "per_camera_setup_ms": per_camera_setup_ms,
+        "per_class": per_class,
+    }
+    if info.get("note"):
+        out["config"]["note"] = info["note"]
+    if full:
+        # counters of the render kernels from the committed rocprofv3 PMC passes of THIS workload (not measured in this run: PMC
+        # collection serialises kernels); scaled to this run's launch size
+        pmc, traffic, valu_frac, lane_util, pmc_src = {}, None, None, None, None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            pmc = json.load(open(tp)).get(workload, {})
+        if pmc:
+            ref_samples = float(pmc["launch"].split("(")[1].split()[0])
+            scale = (float(W) * H * frames_rank / launches) / ref_samples
+            traffic = pmc.get("hbm_bytes_per_launch") and pmc["hbm_bytes_per_launch"] * scale
+            if pmc.get("valu_insts_per_launch"):
+                valu_frac = pmc["valu_insts_per_launch"] * scale / (launch_ms * 1e-3) / VALU_ISSUE_PEAK
+            lane_util = pmc.get("lane_util")
+            pmc_src = f"{pmc.get('source')} @ {pmc.get('commit')} (rocprofv3 --pmc passes of `bench.py --workload {workload}`; " \
+                      f"fabric-side counters, Infinity-Cache hits included)"
+        loaded_per_launch = loaded_bps * samples_rank / launches
+        out["roofline"] = {
+            # bound/achieved/peak/frac: the contract's HBM roofline on the bytes the timed kernels LOAD (the build's own counters,
+            # SURVEY section 8d).  The kernel is not bound by bytes: vector-instruction issue and lane utilisation bound it
+            # (bounded_by, valu_issue_frac, lane_util); its working set is cache-resident.
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": pmc_src,
+            "traffic_over_loaded_bytes": (traffic / loaded_per_launch) if traffic else None,
+            "bounded_by": "valu_issue", "valu_issue_frac": valu_frac, "valu_issue_peak_per_s": VALU_ISSUE_PEAK, "lane_util": lane_util,
+            "kernel": "vp::render_k (a launch = the general kernel and, beside it on a second stream, the light kernel of the "
+                      "pixels whose camera ray meets empty cells only; HIP events from the start of the first to the end of the last)",
+            "launch_ms": launch_ms, "launches": launches,
+            "loaded_bytes_per_sample": loaded_bps,
+            "estimator_bytes_per_sample": estimator_bps,
+            "estimator_equivalent_GBps": estimator_bps * samples_rank / launches / (launch_ms * 1e-3) / 1e9,
+            "reference_estimator_bytes_per_sample": REFERENCE_ESTIMATOR_BYTES_PER_SAMPLE,
+            "lookups_per_sample": {k: counters[k] / n_cnt for k in
+                                   ("density_lookups", "density_loads", "bound_lookups", "opacity_lookups", "env_lookups", "scatters")}}
+    else:
+        out["loaded_GBps"] = achieved
+        out["launch_ms"] = launch_ms
+    if world > 1:
+        mean_k = sum(kerns) / world
+        out["ranks"] = {"wall_s": walls, "kernel_ms": kerns, "balance_max_over_mean": max(kerns) / mean_k if mean_k > 0 else None,
+                        "tile_deal": "vp_tile_owner: every world-th 8x8 tile of a row, rows shifted by a hash of the row index"}
+    if rehearsal:
+        out["config"]["parallelism"] += " (REHEARSAL: all ranks on one GPU, gloo)"
+    out["_image"] = image
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3ref", "c1", "c4s"])
-    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
+    ap.add_argument("--workload", default="c2", choices=WORKLOAD_CHOICES)
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step (weak) / per step (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "both"],
+                    help="weak: spp * N per step (per-GPU work fixed); strong: spp per step whatever N; both: the weak line with "
+                         "the strong measurement inside it")
     ap.add_argument("--rng", default="philox7", choices=["philox", "philox7", "samplerh"],
                     help="philox7 = Philox2x32-7 (default: the fewest rounds Random123 documents as Crush-resistant; oracle parity "
                          "like the others), philox = Philox2x32-10 (the round-1 default, 4-6 %% slower), samplerh = the reference's "
                          "sampler.h streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the second tracked workload (c3) of the N = 1 line")
     ap.add_argument("--dump-image", default=None, help="rank 0 saves the summed HDR image (.npy) -- used by tests")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,143 +328,39 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
 
     import volpath as vp
-    from volpath import scene as vscene
     vp.set_device(local_rank)
     stream = torch.cuda.Stream(device=dev)
     vp.set_stream(stream.cuda_stream)
+    ctx = {"rank": rank, "world": world, "dev": dev, "stream": stream, "rehearsal": rehearsal}
 
-    spp_step = args.spp * world
-    total_steps = args.warmup + args.steps
-    rng_mode = {"philox": vp.RNG_PHILOX, "philox7": vp.RNG_PHILOX7, "samplerh": vp.RNG_SAMPLERH}[args.rng]
-    count_frames = 4 if args.workload == "c2" else 16  # frames of the (untimed) work-counter pass
-    P, info = vscene.setup(args.workload, rng_mode=rng_mode, rank=rank, world=world,
-                           last_frame=max(spp_step * total_steps, count_frames))
-    W, H = P.width, P.height
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    with torch.cuda.stream(stream):
-        acc = torch.zeros(H, W, 4, device=dev, dtype=torch.float32)
-        image = torch.zeros(H, W, 4, device=dev, dtype=torch.float32) if rank == 0 else None
-
-        # work counters (untimed, counting kernel variant): per-sample lookups of THIS build
-        vp.enable_counters(True)
-        vp.read_counters(reset=True)
-        vp.render_frames(acc.data_ptr(), 0, count_frames, P)
-        counters = vp.read_counters(reset=True)
-        vp.enable_counters(False)
-        bytes_per_sample = algorithmic_bytes_per_sample(counters)
-        fetched_bytes_per_sample = algorithmic_bytes_per_sample(counters, loads=True)
-        # where the samples go: the pixel classes of this camera -- general pixels are tracked by the general
-        # kernel, "light" ones (the camera ray meets certified-empty cells only) by the light kernel, and a ray that misses
-        # the box is one environment lookup, evaluated once per pixel and written for every frame
-        try:
-            import numpy as np
-            cls = np.bincount(vp.pixel_table(P)[..., 5].astype(int).ravel(), minlength=3)
-            pixel_classes = {"general": float(cls[0]) / cls.sum(), "light": float(cls[1]) / cls.sum(), "misses_box": float(cls[2]) / cls.sum()}
-        except Exception:
-            pixel_classes = None      # no pixel table in this configuration (tables switched off)
-
-        def step(i):
-            acc.zero_()
-            vp.render_frames(acc.data_ptr(), i * spp_step, spp_step, P)
-            if world > 1 and rehearsal:
-                host = acc.cpu()
-                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-                acc.copy_(host)
-            elif world > 1:
-                dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI
-            if rank == 0:
-                image.add_(acc)
-
-        for i in range(args.warmup):
-            step(i)
-        barrier()
-        vp.render_time_ms(reset=True)
-        t0 = time.perf_counter()
-        for i in range(args.warmup, total_steps):
-            step(i)
-        barrier()
-        dt = time.perf_counter() - t0
-        kern_ms, launches = vp.render_time_ms(reset=True)
-
-    kern_ms, launches = max(kern_ms, 1e-9), max(launches, 1)
-    # per-rank diagnostics: wall time of the timed region and kernel time of each rank (rank order), so that an N > 1 line
-    # shows whether the tile deal balanced the work
-    t = torch.tensor([dt, kern_ms], device=torch.device("cpu") if rehearsal else dev, dtype=torch.float64)
-    per_rank = [t.clone() for _ in range(world)] if world > 1 else [t]
-    if world > 1:
-        dist.all_gather(per_rank, t)
-    walls = [float(x[0]) for x in per_rank]
-    kerns = [float(x[1]) for x in per_rank]
-    dt = max(walls)
+    first = "strong" if args.scaling == "strong" else "weak"
+    out = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, first)
+    strong = None
+    if args.scaling == "both" and world > 1:
+        strong = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, "strong", full=False)
+    secondary = None
+    if world == 1 and args.workload == "c2" and not args.no_secondary:
+        # the reference's LIVE estimator (decomposition tracking) on the same scene, BASELINE configs[2]: tracked every round
+        # beside the headline.  Its brick table goes through LDS because the config names that; the same estimator reading the
+        # reference's per-voxel table from global memory (workload c3ref) is faster (profiles/).
+        secondary = run_workload("c3", args, ctx, args.spp, min(args.steps, 3), 1, "weak", full=False)
 
     if rank == 0:
-        samples_total = float(W) * H * spp_step * args.steps           # all ranks together
-        samples_rank = float(W) * H * args.spp * args.steps             # this rank (its tiles)
-        value = samples_total / dt / 1e6
-        launch_ms = kern_ms / launches
-        bytes_per_launch = bytes_per_sample * samples_rank / launches
-        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        # counters of the render kernel from the committed rocprofv3 PMC passes of THIS workload (not measured in this
-        # run: PMC collection serialises kernels); scaled to this run's launch size
-        pmc, traffic, valu_frac, lane_util, pmc_src = {}, None, None, None, None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            pmc = json.load(open(tp)).get(args.workload, {})
-        if pmc:
-            ref_samples = float(pmc["launch"].split("(")[1].split()[0])
-            scale = (samples_rank / launches) / ref_samples
-            traffic = pmc.get("hbm_bytes_per_launch") and pmc["hbm_bytes_per_launch"] * scale
-            if pmc.get("valu_insts_per_launch"):
-                valu_frac = pmc["valu_insts_per_launch"] * scale / (launch_ms * 1e-3) / VALU_ISSUE_PEAK
-            lane_util = pmc.get("lane_util")
-            pmc_src = f"{pmc.get('source')} @ {pmc.get('commit')} (rocprofv3 --pmc passes of `bench.py --workload {args.workload}`; " \
-                      f"fabric-side counters, Infinity-Cache hits included)"
-        out = {
-            "metric": "Msamples/sec (WxHxspp) + achieved HBM GB/s, Julia 256^3 @ 800x600",
-            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": info["name"], "volume": f"{info['n']}^3 uchar Julia set", "image": f"{W}x{H}",
-                       "spp_per_step": spp_step, "samples_per_step": int(W * H * spp_step),
-                       "estimator": "global_majorant" if info["est"] == vp.EST_GLOBAL else "decomposition",
-                       "bound_brick": info["brick"],
-                       "rng": {"philox": "philox2x32-10", "philox7": "philox2x32-7", "samplerh": "sampler.h"}[args.rng],
-                       "parallelism": f"pixel-tiles x{world}" + (" + RCCL reduce" if world > 1 else ""),
-                       "sky": "Hosek sun/sky bake, setup_sunsky(0.5, 0.2), 1024x512"},
-            # bound/achieved/peak/frac: the contract's HBM roofline on ALGORITHMIC bytes.  What really bounds this kernel is
-            # vector-instruction issue and lane utilisation (bounded_by, valu_issue_frac, lane_util): its working set is
-            # cache-resident and the measured fabric traffic is below the algorithmic bytes.
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
-                         "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic else None,
-                         "bounded_by": "valu_issue", "valu_issue_frac": valu_frac, "valu_issue_peak_per_s": VALU_ISSUE_PEAK,
-                         "lane_util": lane_util,
-                         "kernel": "vp::render_k (a launch = the general kernel and, beside it on a second stream, the light kernel "
-                                   "of the pixels whose camera ray meets empty cells only; HIP events from the start of the "
-                                   "first to the end of the last)",
-                         "launch_ms": launch_ms, "launches": launches,
-                         "algorithmic_bytes_per_sample": bytes_per_sample,
-                         "fetched_bytes_per_sample": fetched_bytes_per_sample,
-                         "fetched_GBps": fetched_bytes_per_sample * samples_rank / launches / (launch_ms * 1e-3) / 1e9,
-                         "reference_estimator_bytes_per_sample": REFERENCE_ESTIMATOR_BYTES_PER_SAMPLE,
-                         "pixel_classes": pixel_classes,
-                         "lookups_per_sample": {k: counters[k] / max(counters["samples"], 1) for k in
-                                                ("density_lookups", "density_loads", "bound_lookups", "opacity_lookups", "env_lookups", "scatters")}},
-        }
-        if world > 1:
-            mean_k = sum(kerns) / world
-            out["ranks"] = {"wall_s": walls, "kernel_ms": kerns, "balance_max_over_mean": max(kerns) / mean_k if mean_k > 0 else None,
-                            "tile_deal": "vp_tile_owner: every world-th 8x8 tile of a row, rows shifted by a hash of the row index"}
+        image = out.pop("_image")
+        if strong:
+            strong.pop("_image")
+            out["strong"] = {k: strong[k] for k in ("value", "unit", "ms_per_step", "scaling", "per_class", "ranks") if k in strong}
+            out["strong"]["spp_per_step"] = strong["config"]["spp_per_step"]
+        if secondary:
+            secondary.pop("_image")
+            out["secondary"] = {"c3": {k: secondary[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "per_class",
+                                                                  "per_camera_setup_ms", "loaded_GBps", "launch_ms")}}
+            out["secondary"]["c3"]["note"] = ("BASELINE configs[2]: 8^3 bricks staged through LDS as the config asks; the LDS table is "
+                                              "SLOWER than the same estimator on the reference's per-voxel table read from global memory "
+                                              "(workload c3ref)")
         if args.dump_image:
             import numpy as np
             np.save(args.dump_image, image.cpu().numpy())
-        if rehearsal:
-            out["config"]["parallelism"] += " (REHEARSAL: all ranks on one GPU, gloo)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

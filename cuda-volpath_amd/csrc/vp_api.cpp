@@ -96,6 +96,9 @@ struct State
     size_t      tiles_cap   = 0;
     unsigned    n_general   = 0, n_light = 0, n_miss = 0;
     std::vector<unsigned char> tiles_key;
+    unsigned*   d_tile_rows = nullptr;    // first owned tile of each tile row (pixlist kernels)
+    unsigned*   d_tile_scratch = nullptr; // per-block class counts + the three totals
+    std::vector<unsigned char> tiles_shape_key;
     // the light kernel runs beside the general one on a stream of its own (ALU-bound waves fill the issue slots the general
     // kernel's waves leave while they wait for cells): one auxiliary stream and two events per launch target
     bool        light_overlap = true;
@@ -108,6 +111,12 @@ struct State
     float4*     d_crawl     = nullptr;
     size_t      crawl_bytes = 0;
     std::vector<unsigned char> crawl_key;
+    // counter-based streams: where a sun shadow ray has only empty cells left (sun_clip_k), per cell; rebuilt when the volume, the
+    // box or the sun direction changes
+    bool        use_sun_clip = true;
+    unsigned short* d_sunclip = nullptr;
+    float       sunclip_ds  = 0.0f;
+    std::vector<unsigned char> sunclip_key;
     float*      d_thr       = nullptr;    // throughput after n null collisions in empty space (light kernel, global majorant)
     float       thr_key[5]  = {};
     bool        thr_valid   = false;
@@ -117,6 +126,10 @@ struct State
     std::vector<hipEvent_t> event_pool;
     double      timed_ms    = 0.0;   // folded launches
     int         timed_n     = 0;     // launches counted (folded or pending or dropped)
+    // the same per pixel class: event pairs around the general kernel, the light kernel and the box-missing fill of each launch
+    struct ClassEv { int cls; hipEvent_t a, b; };
+    std::deque<ClassEv> class_events;
+    double      class_ms[3] = {0.0, 0.0, 0.0};
     // Per-sample staging per launch.  A launch ends with a tail in which only the deepest paths are still running (about
     // 14 ms at 800x600 whatever the launch size), so launches should be long: 128 frames per launch (1 GiB) lose 9 % to
     // tails, 1024 frames (8 GB) 1 %.  288 GB of HBM make that cheap; the cap is also held to a quarter of the free memory
@@ -213,6 +226,7 @@ int ensure_device()
     if (knob("VP_NO_LDS_BOUNDS", 0, 1, v)) G.use_lds_bounds = v == 0;
     if (knob("VP_NO_CRAWL_TABLE", 0, 1, v)) G.use_crawl_table = v == 0;
     if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;
+    if (knob("VP_NO_SUN_CLIP", 0, 1, v)) G.use_sun_clip = v == 0;
     if (knob("VP_NO_LIGHT", 0, 1, v)) G.use_light = v == 0;
     if (knob("VP_NO_LIGHT_OVERLAP", 0, 1, v)) G.light_overlap = v == 0;
     if (knob("VP_NO_LIGHT_LOCAL", 0, 1, v)) G.use_light_local = v == 0;
@@ -237,6 +251,8 @@ int free_volume()
     if (G.d_opacity) HIPCHK(hipFree(G.d_opacity));
     if (G.d_danger) HIPCHK(hipFree(G.d_danger));
     G.d_danger = nullptr;
+    if (G.d_sunclip) HIPCHK(hipFree(G.d_sunclip));
+    G.d_sunclip = nullptr; G.sunclip_key.clear();
     G.d_cells = G.d_bounds = nullptr;
     G.d_opacity   = nullptr;
     G.S.cells_u8  = nullptr;
@@ -423,6 +439,32 @@ hipEvent_t get_event()
     return e;
 }
 void put_event(hipEvent_t e) { if (e) G.event_pool.push_back(e); }
+// a pair of events around one kernel of a launch (per-class kernel time, vp_render_class_time_ms); best effort
+struct ClassTimer
+{
+    int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool ok = false;
+    ClassTimer(int c, hipStream_t s) : cls(c), st(s)
+    {
+        a = get_event(); b = get_event();
+        ok = a && b && hipEventRecord(a, st) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+    }
+    void stop()
+    {
+        if (ok && hipEventRecord(b, st) == hipSuccess) { G.class_events.push_back({cls, a, b}); a = b = nullptr; }
+        else (void)hipGetLastError();
+        put_event(a); put_event(b); a = b = nullptr;
+        while (G.class_events.size() > 3 * kMaxPendingEvents)
+        {
+            auto  ev = G.class_events.front();
+            float ms = 0.0f;
+            G.class_events.pop_front();
+            if (hipEventQuery(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) G.class_ms[ev.cls] += ms;
+            else (void)hipGetLastError();
+            put_event(ev.a); put_event(ev.b);
+        }
+    }
+};
 // keep at most kMaxPendingEvents launch pairs: fold the oldest into the running sum (its elapsed time if the pair
 // has completed; a launch this old that has not is counted without a time rather than waited for)
 void trim_events()
@@ -528,6 +570,41 @@ int ensure_crawl_table(const Param* p, const float4** out)
     return VP_OK;
 }
 
+// Where sun shadow rays end early (vp_kernels.hip sun_clip_k): for the counter-based streams, whose shadow rays draw from
+// sub-streams of their own.  Depends on the volume, its box, the filter mode and the sun direction; one kernel over the
+// non-empty cells (a millisecond at 256^3), synchronously like the other tables.
+int ensure_sun_clip(const unsigned short** out, float* ds)
+{
+    *out = nullptr; *ds = 0.0f;
+    if (!G.use_sun_clip || G.rng == VP_RNG_SAMPLERH || !G.d_danger || !G.linear) return VP_OK;
+    struct K { int nx, ny, nz, quant; float bmin[3], bmax[3], sun[3]; unsigned long long epoch; };
+    std::vector<unsigned char> key(sizeof(K), 0);
+    K* k = reinterpret_cast<K*>(key.data());
+    k->nx = G.S.nx; k->ny = G.S.ny; k->nz = G.S.nz; k->quant = G.quant; k->epoch = G.epoch;
+    memcpy(k->bmin, G.S.bmin, sizeof k->bmin); memcpy(k->bmax, G.S.bmax, sizeof k->bmax); memcpy(k->sun, G.S.sun_dir, sizeof k->sun);
+    if (key != G.sunclip_key || !G.d_sunclip)
+    {
+        if (la_quiesce()) return VP_E_NODEVICE;   // batches in flight read the old table
+        HIPCHK(hipStreamSynchronize(G.stream));
+        const size_t n = (size_t)G.S.nx * G.S.ny * G.S.nz;
+        if (!G.d_sunclip && hipMalloc((void**)&G.d_sunclip, n * sizeof(unsigned short)) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            G.d_sunclip = nullptr;
+            return VP_OK;   // no table: the shadow rays walk to their end, same bits
+        }
+        SceneDev S = G.S;
+        S.linear   = 1;
+        G.sunclip_ds = sun_clip_step(S);
+        launch_sun_clip(S, G.d_danger, G.sunclip_ds, G.d_sunclip, G.stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(G.stream));
+        G.sunclip_key = key;
+    }
+    *out = G.d_sunclip; *ds = G.sunclip_ds;
+    return VP_OK;
+}
+
 // The light kernel of the global-majorant estimator looks the throughput of a path up by its number of null collisions
 // (vp_kernels.hip thr_table_k); the sequence depends on sigma_t, density and g only.
 int ensure_thr_table(const Param* p, const float** out)
@@ -554,7 +631,8 @@ int ensure_thr_table(const Param* p, const float** out)
 // The pixel lists of this context: the pixels of its tiles, tile by tile (row-major tiles, row-major pixels within a tile: the
 // order keeps the rays of a wave in one pencil of the volume), general pixels first, then -- with spectral tracking and a pixel
 // table -- the light class (camera rays that meet certified-empty cells over their whole chord) and the pixels whose camera ray
-// misses the box (pixel_class_k over the pixel table).  Rebuilt when the image size, the shard or the table changes.
+// misses the box.  Built on the GPU (pixlist_*_k: a stable three-way partition of the tile-ordered pixels by the class in the pixel
+// table; the host only reads back the three counts).  Rebuilt when the image size, the shard or the table changes.
 int ensure_pixel_lists(const Param* p, const float4* table, const Shard& sh)
 {
     const bool light = G.use_light && table && G.trk == VP_TRACK_SPECTRAL && !(G.est != VP_EST_GLOBAL && !G.use_light_local);
@@ -562,48 +640,47 @@ int ensure_pixel_lists(const Param* p, const float4* table, const Shard& sh)
     std::vector<unsigned char> key(sizeof(K), 0);
     K* k = reinterpret_cast<K*>(key.data());
     k->w = p->width; k->h = p->height; k->rank = G.rank; k->world = G.world; k->light = light ? 1 : 0;
+    std::vector<unsigned char> shape_key = key;   // what the tile enumeration depends on (not the camera)
     if (light) key.insert(key.end(), G.crawl_key.begin(), G.crawl_key.end());
     if (key == G.tiles_key && G.d_tiles) return VP_OK;
     if (la_quiesce()) return VP_E_NODEVICE;   // batches in flight read the old lists
     HIPCHK(hipStreamSynchronize(G.stream));
-    const unsigned npix = p->width * p->height;
-    std::vector<unsigned char> cls(npix, 0);
-    if (light)
+    const unsigned nblocks = pixel_list_blocks(sh.owned);
+    if (shape_key != G.tiles_shape_key || !G.d_tile_rows)
     {
-        unsigned char* d_cls = nullptr;
-        HIPCHK(hipMalloc((void**)&d_cls, npix));
-        launch_pixel_classes(table, npix, d_cls, G.stream);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(cls.data(), d_cls, npix, hipMemcpyDeviceToHost, G.stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(G.stream);
-        (void)hipFree(d_cls);
-        if (e != hipSuccess) return fail(VP_E_NODEVICE, "pixel classes -> %s", hipGetErrorString(e));
+        // first owned tile of each tile row: depends on the image size and the shard only
+        std::vector<unsigned> rows(sh.tiles_y + 1, 0);
+        for (unsigned ty = 0; ty < sh.tiles_y; ty++)
+        {
+            const unsigned first = (G.rank + G.world - tile_row_shift(ty, G.world)) % G.world;
+            rows[ty + 1] = rows[ty] + (first < sh.tiles_x ? (sh.tiles_x - first + G.world - 1) / G.world : 0u);
+        }
+        if (rows[sh.tiles_y] != sh.owned) return fail(VP_E_STATE, "tile enumeration disagrees with the shard (%u vs %u tiles)", rows[sh.tiles_y], sh.owned);
+        if (G.d_tile_rows) HIPCHK(hipFree(G.d_tile_rows));
+        if (G.d_tile_scratch) HIPCHK(hipFree(G.d_tile_scratch));
+        G.d_tile_rows = G.d_tile_scratch = nullptr; G.tiles_shape_key.clear();
+        HIPCHK(hipMalloc((void**)&G.d_tile_rows, rows.size() * sizeof(unsigned)));
+        HIPCHK(hipMalloc((void**)&G.d_tile_scratch, ((size_t)3 * nblocks + 4) * sizeof(unsigned)));
+        HIPCHK(hipMemcpyAsync(G.d_tile_rows, rows.data(), rows.size() * sizeof(unsigned), hipMemcpyHostToDevice, G.stream));
+        HIPCHK(hipStreamSynchronize(G.stream));   // `rows` goes out of scope
+        G.tiles_shape_key = shape_key;
     }
-    std::vector<unsigned> general, lightv, missv;
-    general.reserve(sh.per_frame);
-    for (unsigned ty = 0; ty < sh.tiles_y; ty++)
-        for (unsigned tx = (G.rank + G.world - tile_row_shift(ty, G.world)) % G.world; tx < sh.tiles_x; tx += G.world)
-            for (unsigned y = ty * 8u; y < ty * 8u + 8u && y < p->height; y++)
-                for (unsigned x = tx * 8u; x < tx * 8u + 8u && x < p->width; x++)
-                {
-                    const unsigned char c = cls[(size_t)y * p->width + x];
-                    (c == 2 ? missv : c == 1 ? lightv : general).push_back(y << 16 | x);
-                }
-    G.n_general = (unsigned)general.size(); G.n_light = (unsigned)lightv.size(); G.n_miss = (unsigned)missv.size();
-    general.insert(general.end(), lightv.begin(), lightv.end());
-    general.insert(general.end(), missv.begin(), missv.end());
-    if (general.size() > G.tiles_cap)
+    if (sh.per_frame > G.tiles_cap)
     {
         if (G.d_tiles) HIPCHK(hipFree(G.d_tiles));
         G.d_tiles = nullptr; G.tiles_cap = 0; G.tiles_key.clear();
-        HIPCHK(hipMalloc((void**)&G.d_tiles, general.size() * sizeof(unsigned)));
-        G.tiles_cap = general.size();
+        HIPCHK(hipMalloc((void**)&G.d_tiles, sh.per_frame * sizeof(unsigned)));
+        G.tiles_cap = sh.per_frame;
     }
-    if (!general.empty())
-    {
-        HIPCHK(hipMemcpyAsync(G.d_tiles, general.data(), general.size() * sizeof(unsigned), hipMemcpyHostToDevice, G.stream));
-        HIPCHK(hipStreamSynchronize(G.stream));
-    }
+    unsigned* d_totals = G.d_tile_scratch + (size_t)3 * nblocks;
+    launch_pixel_lists(p->width, p->height, G.rank, G.world, sh.owned, G.d_tile_rows, light ? table : nullptr, G.d_tile_scratch, d_totals, G.d_tiles, G.stream);
+    HIPCHK(hipGetLastError());
+    unsigned totals[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(totals, d_totals, sizeof totals, hipMemcpyDeviceToHost, G.stream));
+    HIPCHK(hipStreamSynchronize(G.stream));
+    if ((size_t)totals[0] + totals[1] + totals[2] != sh.per_frame)
+        return fail(VP_E_STATE, "pixel lists hold %zu pixels, the shard has %zu", (size_t)totals[0] + totals[1] + totals[2], sh.per_frame);
+    G.n_general = totals[0]; G.n_light = totals[1]; G.n_miss = totals[2];
     G.tiles_key = key;
     return VP_OK;
 }
@@ -642,6 +719,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     rc = ensure_crawl_table(p, &L.crawl);
     if (rc) return rc;
     rc = ensure_pixel_lists(p, L.crawl, sh);
+    if (rc) return rc;
+    rc = ensure_sun_clip(&L.sun_clip, &L.clip_ds);
     if (rc) return rc;
     if (G.est == VP_EST_GLOBAL && G.n_light)
     {
@@ -735,8 +814,10 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                         if (!G.aux_ev[ti][q] && hipEventCreateWithFlags(&G.aux_ev[ti][q], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G.aux_ev[ti][q] = nullptr; }
                     if (G.aux_stream[ti] && G.aux_ev[ti][0] && G.aux_ev[ti][1] && e0 && hipStreamWaitEvent(G.aux_stream[ti], e0, 0) == hipSuccess) ls = G.aux_stream[ti];
                 }
+                ClassTimer ct(1, ls);
                 launch_render_light(S, L, G.est, G.rng, G.quant, G.count, (int)blocks, ls);
                 le = hipGetLastError();
+                ct.stop();
                 if (ls != T.stream && le == hipSuccess)
                 {
                     // the target stream goes on (end-of-launch event, add-kernel) only when the light kernel is done too
@@ -746,8 +827,10 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             }
             else
             {
+                ClassTimer ct(0, T.stream);
                 launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, G.trk, (int)blocks, T.stream);
                 le = hipGetLastError();
+                ct.stop();
             }
         }
         if (G.n_miss && le == hipSuccess)
@@ -757,8 +840,10 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             L.nslots      = G.n_miss;
             L.slot_base   = G.n_general + G.n_light;
             L.total_items = 0;
+            ClassTimer ct(2, T.stream);
             launch_miss_fill(S, L, G.est != VP_EST_GLOBAL, T.stream);
             le = hipGetLastError();
+            ct.stop();
         }
         timed = timed && le == hipSuccess && hipEventRecord(e1, T.stream) == hipSuccess;
         G.timed_n++;
@@ -977,7 +1062,7 @@ void gamma_correct(vp_float4* dst, vp_float4* src, int size, float s, float gamm
 
 // =============================================================================== Part 2
 const char* vp_last_error(void) { return G.err.c_str(); }
-const char* vp_version(void) { return "volpath_hip 0.2 (gfx950)"; }
+const char* vp_version(void) { return "volpath_hip 0.3 (gfx950)"; }
 int vp_device_count(void)
 {
     int n = 0;
@@ -1046,11 +1131,15 @@ int vp_ctx_destroy(vp_ctx* ctx)
             if (sl.stream) (void)hipStreamDestroy(sl.stream);
         }
         for (auto& ev : D.events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        for (auto& ev : D.class_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
         for (auto e : D.event_pool) (void)hipEventDestroy(e);
         if (D.d_stage) (void)hipFree(D.d_stage);
         if (D.d_crawl) (void)hipFree(D.d_crawl);
         if (D.d_thr) (void)hipFree(D.d_thr);
+        if (D.d_sunclip) (void)hipFree(D.d_sunclip);
         if (D.d_tiles) (void)hipFree(D.d_tiles);
+        if (D.d_tile_rows) (void)hipFree(D.d_tile_rows);
+        if (D.d_tile_scratch) (void)hipFree(D.d_tile_scratch);
         for (int i = 0; i < 3; i++)
         {
             if (D.aux_stream[i]) { (void)hipStreamSynchronize(D.aux_stream[i]); (void)hipStreamDestroy(D.aux_stream[i]); }
@@ -1211,6 +1300,79 @@ int vp_render_time_ms(double* total_ms, int* launches, int reset)
     }
     return VP_OK;
 }
+int vp_render_class_time_ms(double ms[3], unsigned pixels[3], int reset)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(G.stream));
+    for (auto& sl : G.la)
+        if (sl.stream) HIPCHK(hipStreamSynchronize(sl.stream));
+    for (int i = 0; i < 3; i++)
+        if (G.aux_stream[i]) HIPCHK(hipStreamSynchronize(G.aux_stream[i]));
+    double tot[3] = {G.class_ms[0], G.class_ms[1], G.class_ms[2]};
+    for (auto& ev : G.class_events)
+    {
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, ev.a, ev.b));
+        tot[ev.cls] += t;
+    }
+    if (ms) for (int i = 0; i < 3; i++) ms[i] = tot[i];
+    if (pixels) { pixels[0] = G.n_general; pixels[1] = G.n_light; pixels[2] = G.n_miss; }
+    if (reset)
+    {
+        for (auto& ev : G.class_events) { put_event(ev.a); put_event(ev.b); }
+        G.class_events.clear();
+        G.class_ms[0] = G.class_ms[1] = G.class_ms[2] = 0.0;
+    }
+    return VP_OK;
+}
+int vp_get_pixel_lists(const Param* p, uint32_t* dst, size_t count, unsigned counts[3])
+{
+    int rc = vp_prepare(p);
+    if (rc) return rc;
+    const size_t n = (size_t)G.n_general + G.n_light + G.n_miss;
+    if (counts) { counts[0] = G.n_general; counts[1] = G.n_light; counts[2] = G.n_miss; }
+    if (dst)
+    {
+        if (count < n) return fail(VP_E_ARG, "pixel lists hold %zu entries", n);
+        if (n) HIPCHK(hipMemcpy(dst, G.d_tiles, n * sizeof(unsigned), hipMemcpyDeviceToHost));
+    }
+    return VP_OK;
+}
+int vp_prepare(const Param* p)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p) return fail(VP_E_ARG, "vp_prepare: null Param");
+    if (!G.have_volume || !G.have_cam) return fail(VP_E_STATE, "vp_prepare needs a volume and a camera");
+    if (p->width == 0 || p->height == 0 || p->width > 65535 || p->height > 65535) return fail(VP_E_ARG, "image %ux%u out of range", p->width, p->height);
+    const Shard sh = shard_of(p);
+    if (sh.per_frame == 0)
+    {
+        // a shard without a tile (more ranks than tiles): empty lists
+        G.n_general = G.n_light = G.n_miss = 0; G.tiles_key.clear();
+        return VP_OK;
+    }
+    const float4* table = nullptr;
+    rc = ensure_crawl_table(p, &table);
+    if (rc) return rc;
+    rc = ensure_pixel_lists(p, table, sh);
+    if (rc) return rc;
+    if (G.have_sun)
+    {
+        const unsigned short* sc = nullptr; float ds = 0.0f;
+        rc = ensure_sun_clip(&sc, &ds);
+        if (rc) return rc;
+    }
+    if (G.est == VP_EST_GLOBAL && G.n_light)
+    {
+        const float* thr = nullptr;
+        rc = ensure_thr_table(p, &thr);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(G.stream));
+    return VP_OK;
+}
 int vp_get_bound_table(void* dst, size_t bytes, int* bnx, int* bny, int* bnz, int* brick, int* radius)
 {
     if (!G.have_volume) return fail(VP_E_STATE, "no volume");
@@ -1240,6 +1402,22 @@ int vp_get_pixel_table(const Param* p, float* dst, size_t count)
     if (rc) return rc;
     if (!t) return fail(VP_E_STATE, "no pixel table in this configuration (point filtering, or the tables are switched off)");
     HIPCHK(hipMemcpy(dst, t, need * sizeof(float), hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+int vp_get_sun_clip_table(unsigned short* dst, size_t count, float* step)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!G.have_volume || !G.have_sun) return fail(VP_E_STATE, "vp_get_sun_clip_table needs a volume and a sun");
+    const size_t n = (size_t)G.S.nx * G.S.ny * G.S.nz;
+    if (!dst || count < n) return fail(VP_E_ARG, "sun clip table needs %zu entries", n);
+    const unsigned short* t = nullptr;
+    float ds = 0.0f;
+    rc = ensure_sun_clip(&t, &ds);
+    if (rc) return rc;
+    if (!t) return fail(VP_E_STATE, "no sun clip table in this configuration (sampler.h streams, point filtering, or switched off)");
+    HIPCHK(hipMemcpy(dst, t, n * sizeof(unsigned short), hipMemcpyDeviceToHost));
+    if (step) *step = ds;
     return VP_OK;
 }
 int vp_get_null_collision_table(const Param* p, float* dst, size_t count)
@@ -1395,6 +1573,23 @@ int vp_julia_voxelize(int n, unsigned char* host_out)
     HIPCHK(hipStreamSynchronize(G.stream));
     HIPCHK(hipMemcpy(host_out, d, total, hipMemcpyDeviceToHost));
     HIPCHK(hipFree(d));
+    return VP_OK;
+}
+
+int vp_cloud_voxelize(int n, uint32_t seed, float* host_out)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n < 1 || n > 1024 || !host_out) return fail(VP_E_ARG, "bad cloud grid size %d", n);
+    size_t total = (size_t)n * n * n;
+    float* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, total * sizeof(float)));
+    launch_cloud(d, n, seed, G.stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(G.stream);
+    if (e == hipSuccess) e = hipMemcpy(host_out, d, total * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(VP_E_NODEVICE, "vp_cloud_voxelize -> %s", hipGetErrorString(e));
     return VP_OK;
 }
 

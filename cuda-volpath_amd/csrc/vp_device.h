@@ -104,6 +104,10 @@ struct RngSamplerH
     __device__ __forceinline__ float next_b() { return next(); }
     // discard n draws (values that cannot influence the path: the restart crawl in front of the volume)
     __device__ __forceinline__ void skip(unsigned n) { for (unsigned i = 0; i < n; i++) word(); }
+    // the reference's stream is sequential: a shadow ray draws from it like everything else
+    static constexpr bool kShadowSubstream = false;
+    __device__ __forceinline__ void enter_shadow(unsigned) {}
+    __device__ __forceinline__ void leave_shadow() {}
 };
 
 // Philox2x32-R (Salmon et al., SC'11; R = 10 or 7), numbered in PAIRS of draws: next_a() computes
@@ -118,7 +122,7 @@ struct RngPhiloxR
     unsigned w1;              // second word of the current pair
     __device__ __forceinline__ void init(unsigned px, unsigned py, unsigned frame, unsigned key0, unsigned key1)
     {
-        pix = (px << 16) | py; key = (frame ^ key0) + key1; pair = 0; w1 = 0;
+        pix = (px << 16) | py; key = (frame ^ key0) + key1; pair = 0; w1 = 0; saved = 0;
     }
     __device__ __forceinline__ float next_a()
     {
@@ -139,6 +143,14 @@ struct RngPhiloxR
     __device__ __forceinline__ float next_b() { return u2f(0x3f800000u | (w1 >> 9)) - 1.0f; }
     // discard n pairs: the counter moves, nothing is computed
     __device__ __forceinline__ void skip(unsigned n) { pair += n; }
+    // A shadow ray draws from a sub-stream of its own: pair indices 0x80000000 + (id << 20) + 0, 1, 2, ... with
+    // id = 2 * (scatter depth) + (0 sun ray, 1 environment ray of the one-sample MIS); the path's own stream goes on
+    // afterwards where it stood (oracle: rng_enter_shadow).  What the path draws after a light estimate then does not depend
+    // on the number of steps the estimate took, so a shadow ray may stop as soon as nothing can change its result any more.
+    static constexpr bool kShadowSubstream = true;
+    unsigned saved;
+    __device__ __forceinline__ void enter_shadow(unsigned id) { saved = pair; pair = 0x80000000u + (id << 20); }
+    __device__ __forceinline__ void leave_shadow() { pair = saved; }
 };
 typedef RngPhiloxR<10> RngPhilox;   // VP_RNG_PHILOX
 typedef RngPhiloxR<7>  RngPhilox7;  // VP_RNG_PHILOX7: Random123's smallest Crush-resistant round count

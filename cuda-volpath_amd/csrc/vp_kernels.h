@@ -76,6 +76,10 @@ struct LaunchDev
     unsigned key0, key1;    // Philox key
     unsigned wait_lanes, wait_iters;  // inner-loop exit policy (VP_WAIT_LANES / VP_WAIT_ITERS)
     unsigned setup_lanes;   // lanes that must ask for a segment set-up before it runs mid-pass (VP_SETUP_LANES; 1 = at every step)
+    // Counter-based streams: per cell of the volume, the distance (in steps of clip_ds, 0xffff = unknown) beyond which a ray from
+    // anywhere in the cell toward the sun meets empty cells only (sun_clip_k); a sun shadow ray ends there.  Null = walk to the end.
+    const unsigned short* sun_clip;
+    float    clip_ds;
     const float* thr_table; // light kernel of the global-majorant estimator: thr_table[n] = throughput after n null collisions in empty
     unsigned thr_n;         // space (thr_table_k: a function of n alone there), n < thr_n; beyond the table the recurrence is run
 };
@@ -87,12 +91,18 @@ void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng
 void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimator, hipStream_t st);
 // throughput of an unscattered global-majorant path after n null collisions with density +0, n = 0..count-1 (thr_table_k)
 void launch_thr_table(const ParamDev& P, float* table, unsigned count, hipStream_t st);
-void launch_pixel_classes(const float4* table, unsigned npixels, unsigned char* out, hipStream_t st);
+// the rank's pixel lists, class by class, on the GPU (pixlist_*_k): d_row_start[tiles_y + 1] = first owned tile of each tile row,
+// d_block_counts[3 * pixel_list_blocks(ntiles)] scratch, d_totals[3] = pixels per class (general, light, box-missing)
+inline unsigned pixel_list_blocks(unsigned ntiles) { return (unsigned)(((size_t)ntiles * 64 + 1023) / 1024); }
+void launch_pixel_lists(unsigned width, unsigned height, unsigned rank, unsigned world, unsigned ntiles, const unsigned* d_row_start,
+                        const float4* table, unsigned* d_block_counts, unsigned* d_totals, unsigned* d_out, hipStream_t st);
 void launch_env_tables(const float4* env, int w, int h, float* lum, float* row_sum, float* cdf_x, float* cdf_y, float* pdfnorm_alt,
                        hipStream_t st);
 void launch_crawl_table(const SceneDev& S, bool quant, unsigned width, unsigned height, bool control_draw, const unsigned char* danger, float4* table,
                         hipStream_t st);
 void launch_danger(const SceneDev& S, bool quant, unsigned char* out, hipStream_t st);
+float sun_clip_step(const SceneDev& S);  // the table's distance unit: a quarter of the smallest cell edge
+void launch_sun_clip(const SceneDev& S, const unsigned char* danger, float ds, unsigned short* out, hipStream_t st);
 void launch_empty_table(const SceneDev& S, unsigned width, unsigned height, const unsigned char* danger, float4* table, hipStream_t st);
 void launch_reduce(const LaunchDev& L, hipStream_t st);
 void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, hipStream_t st);
@@ -101,6 +111,7 @@ void launch_opacity(const SceneDev& S, bool quant, const float dir[3], float* ou
 void launch_build_bounds(const void* d_vol, bool quant, void* d_out, void* d_tmp_a, void* d_tmp_b, int nx, int ny, int nz, int radius, int brick,
                          hipStream_t st);
 void launch_julia(unsigned char* grid, int n, hipStream_t st);
+void launch_cloud(float* grid, int n, unsigned seed, hipStream_t st);
 void launch_scale(float4* dst, const float4* src, int size, float s, hipStream_t st);
 void launch_gamma(float4* dst, const float4* src, int size, float s, float inv_gamma, hipStream_t st);
 void launch_accumulate(float4* dst, const float4* src, size_t n, hipStream_t st);

@@ -17,6 +17,7 @@
 // (MIS = false, the shipped build) or 0 (MIS = true).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -143,6 +144,9 @@ void render_k(SceneDev S, LaunchDev L)
     // the unscattered camera ray is certified to run through empty cells (all eight texels of every fetch zero) up to this
     // distance from the current ray / segment origin (empty_table_k, crawl_table_k); 0 once the path has scattered
     float    t_empty = 0.0f;
+    // COUNT build only: where the timed kernel ends the current sun shadow ray (it walks on here, so that density_lookups stays
+    // the estimator's count, and stops counting loads)
+    float    t_clip = 1e30f;
     unsigned long long c_load = 0;
 
     unsigned long long c_den = 0, c_bnd = 0, c_opa = 0, c_env = 0, c_sca = 0, c_smp = 0;
@@ -184,7 +188,8 @@ void render_k(SceneDev S, LaunchDev L)
         const f3 sun_dir   = f3{S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]};
         const f3 sun_power = f3{S.sun_power[0], S.sun_power[1], S.sun_power[2]};
         // Tr_spectral set-up kernel.cu:763-780: shadow ray from the collision point ro toward `end`
-        auto start_shadow = [&](f3 end, float inv_s, float den) __attribute__((always_inline)) {
+        // stage: 0 = the sun ray, 1 = the environment ray of the one-sample MIS
+        auto start_shadow = [&](f3 end, float inv_s, float den, unsigned stage) __attribute__((always_inline)) {
             f3    sd = normalize(end - ro);
             float tn, tf;
             bool  hitv = intersect_box(ro, sd, S, tn, tf);
@@ -204,6 +209,27 @@ void render_k(SceneDev S, LaunchDev L)
                 inv_sigma   = inv_s;
                 cur_density = den;
                 st          = ST_SHADOW;
+                rng.enter_shadow(2u * (unsigned)nsc + stage);
+                if (COUNT) t_clip = 1e30f;
+                if (RNG::kShadowSubstream && stage == 0u && L.sun_clip)
+                {
+                    // Beyond sun_clip[cell of ro] * clip_ds every fetch of this ray filters eight zero texels (sun_clip_k): no
+                    // channel can terminate there any more, whatever is drawn, so the ray's result is known when it gets
+                    // there.  Its draws come from a sub-stream of their own: nothing else depends on how many it makes.
+                    f3    pl = to_local(S, ro);
+                    int   ci, cj, ck;
+                    float w_;
+                    axis_linear(pl.x, S.nx, ci, w_);
+                    axis_linear(pl.y, S.ny, cj, w_);
+                    axis_linear(pl.z, S.nz, ck, w_);
+                    const unsigned n = L.sun_clip[(size_t)((unsigned)ci + __umul24((unsigned)S.nx, (unsigned)cj + __umul24((unsigned)S.ny, (unsigned)ck)))];
+                    if (n != 0xffffu)
+                    {
+                        const float tc = (float)n * L.clip_ds;
+                        if (COUNT) t_clip = tc;
+                        else t_end = fminf(t_end, tc);
+                    }
+                }
             }
         };
         // the path goes on with a new segment; loop bounds kernel.cu:34 with :2015 / :1332 / :1716
@@ -286,7 +312,7 @@ void render_k(SceneDev S, LaunchDev L)
                 st     = EV_NEE;
             }
             else
-                start_shadow(sun_dir * 1e10f, 1.0f / stp2, dp2);
+                start_shadow(sun_dir * 1e10f, 1.0f / stp2, dp2, 0u);
         }
 #pragma unroll
         for (int pass = 0; pass < (MIS ? 2 : 1); pass++)
@@ -326,7 +352,7 @@ void render_k(SceneDev S, LaunchDev L)
                     float weight = wa / (wa + wb) / P_phase;
                     nee_c = envc;
                     nee_t = thr3 * weight;
-                    start_shadow(brdf_dir * 1e10f, sh_inv_sigma, sh_density);
+                    start_shadow(brdf_dir * 1e10f, sh_inv_sigma, sh_density, 1u);
                 }
                 else
                 {
@@ -350,7 +376,7 @@ void render_k(SceneDev S, LaunchDev L)
                         float weight = wa / (wa + wb) / P_envmap;
                         nee_c = envc;
                         nee_t = ((thr3 * pdf_brdf_virtual) / pdf_env) * weight;
-                        start_shadow(envmap_dir * 1e10f, sh_inv_sigma, sh_density);
+                        start_shadow(envmap_dir * 1e10f, sh_inv_sigma, sh_density, 1u);
                     }
                 }
             }
@@ -634,6 +660,7 @@ void render_k(SceneDev S, LaunchDev L)
                         // Tr_spectral returns 1 - terminated flags (kernel.cu:807)
                         nee_a = f3{(float)(1 - (terms & 1)), (float)(1 - ((terms >> 1) & 1)), (float)(1 - ((terms >> 2) & 1))};
                         st    = EV_NEE;
+                        rng.leave_shadow();
                     }
                     else if (LOCAL)
                     {
@@ -669,7 +696,7 @@ void render_k(SceneDev S, LaunchDev L)
                         if (shadow || !(dist < t_empty))
                         {
                             den = sample_density01<QUANT>(S, p) * cur_density;  // vol_sigma_t kernel.cu:682-695
-                            if (COUNT) c_load++;
+                            if (COUNT && !(shadow && dist >= t_clip)) c_load++;
                         }
                     }
                     else
@@ -679,7 +706,7 @@ void render_k(SceneDev S, LaunchDev L)
                         if (shadow || !(dist < t_empty))
                         {
                             den = sample_density01<QUANT>(S, p) * cur_density;  // vol_sigma_t kernel.cu:682-695
-                            if (COUNT) c_load++;
+                            if (COUNT && !(shadow && dist >= t_clip)) c_load++;
                         }
                     }
                     float e   = rng.next_b();
@@ -689,7 +716,7 @@ void render_k(SceneDev S, LaunchDev L)
                         // scalar delta tracking: kernel.cu:2137-2142 / :745-748 (Tr stops AT its collision, no further draw)
                         if (e < den * inv_sigma)
                         {
-                            if (shadow) { nee_a = f3{0.0f, 0.0f, 0.0f}; st = EV_NEE; }
+                            if (shadow) { nee_a = f3{0.0f, 0.0f, 0.0f}; st = EV_NEE; rng.leave_shadow(); }
                             else { ro = p; st = EV_SCATTER; }
                         }
                     }
@@ -911,6 +938,53 @@ __global__ __launch_bounds__(256) void danger_k(SceneDev S, unsigned char* out)
     }
     out[idx] = (unsigned char)((any ? 1 : 0) | (self ? 2 : 0));
 }
+// ---- where a sun shadow ray has nothing left to meet (counter-based streams; render_k start_shadow).
+// Per NON-EMPTY cell c (a collision needs a positive density, i.e. a non-empty cell; the others are marked 0xffff = unknown): the
+// ray from the cell's centre toward the sun is marched in steps of ds = a quarter of the smallest cell edge until it is a whole
+// cell outside the box, and the last sample whose cell has a non-empty cell in its 3x3x3 neighbourhood (danger_k bit 0) is
+// recorded, plus two steps.  Claim: for ANY start point p in cell c, every point p + t * d with t >= out[c] * ds lies in an empty
+// cell (all eight texels zero: a trilinear fetch there returns exactly +0).  Proof: p differs from the centre by at most half a
+// cell per axis (three quarters in the first cell of an axis, which also takes the half texel below the first texel centre; the
+// representative point is the middle of the cell's range in continuous cell coordinates), p + t * d from the marched ray's point
+// at the same t by the same vector, and that point from the nearest sample by at most ds / 2 = an eighth of a cell: less than one
+// cell per axis in all, so the cell index differs by at most one per axis from that of a sample beyond the recorded one, whose
+// whole 3x3x3 neighbourhood is empty.  The shadow ray's own direction normalize(sun * 1e10 - p) differs from the marched
+// one by 1e-7 (the origin's share of 1e10), i.e. by less than 1e-6 of the box over the whole chord.
+__global__ __launch_bounds__(256) void sun_clip_k(SceneDev S, const unsigned char* danger, float ds, unsigned short* out)
+{
+    const size_t n   = (size_t)S.nx * S.ny * S.nz;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    if (!(danger[idx] & 2)) { out[idx] = 0xffffu; return; }
+    const int i = (int)(idx % S.nx), j = (int)((idx / S.nx) % S.ny), k = (int)(idx / ((size_t)S.nx * S.ny));
+    // the cell's range in continuous cell coordinates xb = p * N - 0.5 (cell index = clamp(floor(xb))) and its middle
+    auto mid = [](int c, int nc) -> float {
+        const float lo = c == 0 ? -0.5f : (float)c, hi = c == nc - 1 ? (float)nc - 0.5f : (float)c + 1.0f;
+        return 0.5f * (lo + hi);
+    };
+    const f3 bmin = f3{S.bmin[0], S.bmin[1], S.bmin[2]};
+    const f3 ext  = f3{S.bmax[0], S.bmax[1], S.bmax[2]} - bmin;
+    const f3 pl   = f3{(mid(i, S.nx) + 0.5f) / (float)S.nx, (mid(j, S.ny) + 0.5f) / (float)S.ny, (mid(k, S.nz) + 0.5f) / (float)S.nz};
+    const f3 o    = pl * ext + bmin;
+    const f3 sun  = f3{S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]};
+    const f3 d    = normalize(sun * 1e10f - o);
+    int      last = -1;
+    unsigned m    = 0;
+    for (; m < 65000u; m++)
+    {
+        const f3    q  = to_local(S, o + d * ((float)m * ds));
+        const float xa = fma_(q.x, (float)S.nx, -0.5f), xb = fma_(q.y, (float)S.ny, -0.5f), xc = fma_(q.z, (float)S.nz, -0.5f);
+        if (!(xa >= -1.5f && xa <= (float)S.nx + 0.5f && xb >= -1.5f && xb <= (float)S.ny + 0.5f && xc >= -1.5f && xc <= (float)S.nz + 0.5f)) break;
+        int   a, b, c;
+        float w_;
+        axis_linear(q.x, S.nx, a, w_);
+        axis_linear(q.y, S.ny, b, w_);
+        axis_linear(q.z, S.nz, c, w_);
+        if (danger[(size_t)a + (size_t)S.nx * ((size_t)b + (size_t)S.ny * c)] & 1) last = (int)m;
+    }
+    // a march that did not leave the box (never on a sane scene, or a NaN direction): no certificate rather than a wrong one
+    out[idx] = (m >= 65000u || !(d.x == d.x && d.y == d.y && d.z == d.z)) ? 0xffffu : (unsigned short)min(last + 2, 0xfffe);
+}
 // distance from the origin up to which the ray (o, d) runs through certified-empty cells; 0 = no certificate.
 // cls: 0 general, 1 the certificate covers the whole chord (the path can never collide), 2 the ray misses the box (the
 // integrator's own test, intersectBox kernel.cu:654-680, says so: the path is the environment lookup alone)
@@ -1014,12 +1088,108 @@ __global__ __launch_bounds__(256) void reduce_stage_k(LaunchDev L)
     L.out[idx] = a;
 }
 
-// class of each pixel from the pixel table: 1 = light (its camera ray misses the box or meets certified-empty cells over its
-// whole chord), 0 = general
-__global__ void pixel_class_k(const float4* table, unsigned npixels, unsigned char* out)
+// ---- the pixel lists of a rank, built on the GPU (vp_api.cpp ensure_pixel_lists): a stable partition of the rank's pixels --
+// those of its 8x8 tiles, tile by tile (row-major tiles, row-major pixels within a tile) -- by pixel class (0 general, 1 the whole
+// chord is certified empty, 2 the camera ray misses the box; pixel table [1].y).  Padded slot s = 64 * (n-th owned tile) + 8 * row +
+// column; slots outside the image (partial edge tiles) are dropped.  Three small kernels: per-block class counts, an exclusive scan
+// of the block counts (one workgroup), and the scatter with wave-ballot ranks, so that an orbiting camera pays no host loop.
+struct PixListDev
 {
-    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npixels) out[i] = (unsigned char)table[2 * (size_t)i + 1].y;  // 0 general, 1 certified-empty chord, 2 misses the box
+    unsigned width, height, rank, world, tiles_x, tiles_y;
+    unsigned ntiles;            // owned tiles
+    const unsigned* row_start;  // [tiles_y + 1]: index of the first owned tile of each tile row (camera-independent, from the host)
+    const float4*   table;      // pixel table, or null = every pixel is general
+};
+#define VP_PIXLIST_BLOCK 1024
+__device__ __forceinline__ unsigned pixlist_slot(const PixListDev& D, unsigned s, unsigned& pix)
+{
+    // class of padded slot s (3 = not a pixel of the image) and its pixel y << 16 | x
+    const unsigned t = s >> 6;
+    pix = 0;
+    if (t >= D.ntiles) return 3u;
+    // the tile row: the last ty with row_start[ty] <= t
+    unsigned lo = 0, hi = D.tiles_y;
+    while (hi - lo > 1u)
+    {
+        const unsigned mid = (lo + hi) >> 1;
+        if (D.row_start[mid] <= t) lo = mid; else hi = mid;
+    }
+    const unsigned ty = lo;
+    const unsigned first = (D.rank + D.world - tile_row_shift(ty, D.world)) % D.world;
+    const unsigned tx = first + (t - D.row_start[ty]) * D.world;
+    const unsigned x = tx * 8u + (s & 7u), y = ty * 8u + ((s >> 3) & 7u);
+    if (x >= D.width || y >= D.height) return 3u;
+    pix = y << 16 | x;
+    if (!D.table) return 0u;
+    const unsigned c = (unsigned)D.table[2 * ((size_t)x + (size_t)y * D.width) + 1].y;
+    return c > 2u ? 0u : c;
+}
+__global__ __launch_bounds__(VP_PIXLIST_BLOCK) void pixlist_count_k(PixListDev D, unsigned* block_counts)
+{
+    __shared__ unsigned cnt[3];
+    if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned pix;
+    const unsigned c = pixlist_slot(D, blockIdx.x * VP_PIXLIST_BLOCK + threadIdx.x, pix);
+    for (unsigned k = 0; k < 3; k++)
+    {
+        const unsigned long long m = __ballot(c == k);
+        if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&cnt[k], (unsigned)__popcll(m));
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) block_counts[3 * blockIdx.x + threadIdx.x] = cnt[threadIdx.x];
+}
+// exclusive scan of the per-block counts, class by class, in place; totals[3] = pixels per class.  One workgroup.
+__global__ __launch_bounds__(VP_PIXLIST_BLOCK) void pixlist_scan_k(unsigned* block_counts, unsigned nblocks, unsigned* totals)
+{
+    __shared__ unsigned part[VP_PIXLIST_BLOCK];
+    __shared__ unsigned carry;
+    for (unsigned k = 0; k < 3; k++)
+    {
+        if (threadIdx.x == 0) carry = 0;
+        __syncthreads();
+        for (unsigned base = 0; base < nblocks; base += VP_PIXLIST_BLOCK)
+        {
+            const unsigned i = base + threadIdx.x;
+            const unsigned v = i < nblocks ? block_counts[3 * i + k] : 0u;
+            part[threadIdx.x] = v;
+            __syncthreads();
+            // Hillis-Steele inclusive scan of the chunk
+            for (unsigned off = 1; off < VP_PIXLIST_BLOCK; off <<= 1)
+            {
+                const unsigned a = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+                __syncthreads();
+                part[threadIdx.x] += a;
+                __syncthreads();
+            }
+            if (i < nblocks) block_counts[3 * i + k] = carry + part[threadIdx.x] - v;
+            __syncthreads();
+            if (threadIdx.x == 0) carry += part[VP_PIXLIST_BLOCK - 1];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) totals[k] = carry;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(VP_PIXLIST_BLOCK) void pixlist_write_k(PixListDev D, const unsigned* block_offsets, const unsigned* totals, unsigned* out)
+{
+    __shared__ unsigned wave_cnt[VP_PIXLIST_BLOCK / 64][3];
+    unsigned pix;
+    const unsigned c    = pixlist_slot(D, blockIdx.x * VP_PIXLIST_BLOCK + threadIdx.x, pix);
+    const unsigned wave = threadIdx.x >> 6;
+    unsigned rank_in_wave = 0;
+    for (unsigned k = 0; k < 3; k++)
+    {
+        const unsigned long long m = __ballot(c == k);
+        if (c == k) rank_in_wave = lane_rank(m);
+        if ((threadIdx.x & 63u) == 0) wave_cnt[wave][k] = (unsigned)__popcll(m);
+    }
+    __syncthreads();
+    if (c > 2u) return;
+    unsigned before = 0;
+    for (unsigned w = 0; w < wave; w++) before += wave_cnt[w][c];
+    const unsigned class_base = c == 0 ? 0u : c == 1 ? totals[0] : totals[0] + totals[1];
+    out[class_base + block_offsets[3 * blockIdx.x + c] + before + rank_in_wave] = pix;
 }
 
 // The samples of a pixel whose camera ray misses the box are the same in every frame: set-up finds no hit (intersectBox,
@@ -1227,6 +1397,56 @@ __global__ void julia_k(unsigned char* grid, int n)
     grid[idx] = iter > 27 ? 255 : 0;
 }
 
+// A FLAGGED SYNTHETIC cloud for the 512^3 workloads ("fBm-thresholded 512^3 cloud ... parameters
+// logged -- never silently substituted"; the WDAS data set and OpenVDB do not exist in this image): five octaves of value noise
+// on hashed lattices (wang_hash of the lattice point and the seed), thresholded, with a soft spherical edge; float densities
+// in [0,1], NOT binary, so that the local minima / maxima of the bound table differ and the control component is active.
+// Every operation is a binary32 add / multiply / divide / sqrt / floor in a fixed order: the oracle's restatement
+// (vpo_cloud_voxelize) computes the same bits.
+__device__ __forceinline__ float cloud_lattice(int ix, int iy, int iz, unsigned seed)
+{
+    const unsigned h = wang_hash(((unsigned)ix * 73856093u) ^ ((unsigned)iy * 19349663u) ^ ((unsigned)iz * 83492791u) ^ seed);
+    return (float)(h & 0xffffffu) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float cloud_noise(float x, float y, float z, unsigned seed)
+{
+    const float fx = __builtin_floorf(x), fy = __builtin_floorf(y), fz = __builtin_floorf(z);
+    const int   ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    float tx = x - fx, ty = y - fy, tz = z - fz;
+    tx = (tx * tx) * (3.0f - 2.0f * tx);
+    ty = (ty * ty) * (3.0f - 2.0f * ty);
+    tz = (tz * tz) * (3.0f - 2.0f * tz);
+    const float c000 = cloud_lattice(ix, iy, iz, seed), c100 = cloud_lattice(ix + 1, iy, iz, seed);
+    const float c010 = cloud_lattice(ix, iy + 1, iz, seed), c110 = cloud_lattice(ix + 1, iy + 1, iz, seed);
+    const float c001 = cloud_lattice(ix, iy, iz + 1, seed), c101 = cloud_lattice(ix + 1, iy, iz + 1, seed);
+    const float c011 = cloud_lattice(ix, iy + 1, iz + 1, seed), c111 = cloud_lattice(ix + 1, iy + 1, iz + 1, seed);
+    const float x00 = c000 + (c100 - c000) * tx, x10 = c010 + (c110 - c010) * tx;
+    const float x01 = c001 + (c101 - c001) * tx, x11 = c011 + (c111 - c011) * tx;
+    const float y0 = x00 + (x10 - x00) * ty, y1 = x01 + (x11 - x01) * ty;
+    return y0 + (y1 - y0) * tz;
+}
+__global__ void cloud_k(float* grid, int n, unsigned seed)
+{
+    size_t total = (size_t)n * n * n;
+    size_t idx   = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int   i = (int)(idx % n), j = (int)((idx / n) % n), k = (int)(idx / ((size_t)n * n));
+    float fn = (float)n;
+    float px = ((float)i + 0.5f) / fn * 2.0f - 1.0f, py = ((float)j + 0.5f) / fn * 2.0f - 1.0f, pz = ((float)k + 0.5f) / fn * 2.0f - 1.0f;
+    float sum = 0.0f, amp = 0.5f, freq = 2.0f;
+    for (int o = 0; o < 5; o++)
+    {
+        sum = sum + amp * cloud_noise(px * freq + 17.0f, py * freq + 17.0f, pz * freq + 17.0f, seed + (unsigned)o * 0x9E3779B9u);
+        amp = amp * 0.5f;
+        freq = freq * 2.0f;
+    }
+    float v = (sum * (1.0f / 0.96875f) - 0.44f) * 3.0f;   // octave amplitudes sum to 0.96875
+    v = fminf(fmaxf(v, 0.0f), 1.0f);
+    float r = __builtin_sqrtf(px * px + py * py + pz * pz);
+    float edge = fminf(fmaxf((1.2f - r) * (1.0f / 0.4f), 0.0f), 1.0f);
+    grid[idx] = v * edge;
+}
+
 // dst += src (float4): sums per-shard accumulators of several contexts on one device
 __global__ void accumulate_k(float4* dst, const float4* src, size_t n)
 {
@@ -1412,9 +1632,17 @@ void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimato
 {
     hipLaunchKernelGGL(miss_fill_k, dim3((L.nslots + 255) / 256), dim3(256), 0, st, S, L, local_estimator ? 1 : 0);
 }
-void launch_pixel_classes(const float4* table, unsigned npixels, unsigned char* out, hipStream_t st)
+void launch_pixel_lists(unsigned width, unsigned height, unsigned rank, unsigned world, unsigned ntiles, const unsigned* d_row_start,
+                        const float4* table, unsigned* d_block_counts, unsigned* d_totals, unsigned* d_out, hipStream_t st)
 {
-    hipLaunchKernelGGL(pixel_class_k, dim3((npixels + 255) / 256), dim3(256), 0, st, table, npixels, out);
+    PixListDev D;
+    D.width = width; D.height = height; D.rank = rank; D.world = world;
+    D.tiles_x = (width + 7) / 8; D.tiles_y = (height + 7) / 8; D.ntiles = ntiles; D.row_start = d_row_start; D.table = table;
+    const unsigned nblocks = pixel_list_blocks(ntiles);
+    if (!nblocks) return;
+    hipLaunchKernelGGL(pixlist_count_k, dim3(nblocks), dim3(VP_PIXLIST_BLOCK), 0, st, D, d_block_counts);
+    hipLaunchKernelGGL(pixlist_scan_k, dim3(1), dim3(VP_PIXLIST_BLOCK), 0, st, d_block_counts, nblocks, d_totals);
+    hipLaunchKernelGGL(pixlist_write_k, dim3(nblocks), dim3(VP_PIXLIST_BLOCK), 0, st, D, (const unsigned*)d_block_counts, (const unsigned*)d_totals, d_out);
 }
 
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
@@ -1559,6 +1787,16 @@ void launch_danger(const SceneDev& S, bool quant, unsigned char* out, hipStream_
     if (quant) hipLaunchKernelGGL(danger_k<true>, g, dim3(256), 0, st, S, out);
     else hipLaunchKernelGGL(danger_k<false>, g, dim3(256), 0, st, S, out);
 }
+float sun_clip_step(const SceneDev& S)
+{
+    const float cx = (S.bmax[0] - S.bmin[0]) / (float)S.nx, cy = (S.bmax[1] - S.bmin[1]) / (float)S.ny, cz = (S.bmax[2] - S.bmin[2]) / (float)S.nz;
+    return 0.25f * std::fmin(std::fmin(cx, cy), cz);
+}
+void launch_sun_clip(const SceneDev& S, const unsigned char* danger, float ds, unsigned short* out, hipStream_t st)
+{
+    size_t n = (size_t)S.nx * S.ny * S.nz;
+    hipLaunchKernelGGL(sun_clip_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, danger, ds, out);
+}
 void launch_empty_table(const SceneDev& S, unsigned width, unsigned height, const unsigned char* danger, float4* table, hipStream_t st)
 {
     unsigned n = width * height;
@@ -1615,6 +1853,11 @@ void launch_julia(unsigned char* grid, int n, hipStream_t st)
 {
     size_t total = (size_t)n * n * n;
     hipLaunchKernelGGL(julia_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, grid, n);
+}
+void launch_cloud(float* grid, int n, unsigned seed, hipStream_t st)
+{
+    size_t total = (size_t)n * n * n;
+    hipLaunchKernelGGL(cloud_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, grid, n, seed);
 }
 void launch_scale(float4* dst, const float4* src, int size, float s, hipStream_t st)
 {

@@ -24,8 +24,8 @@ PART1_SYMBOLS = ["init_cuda", "set_texture_filter_mode", "free_cuda_buffers", "p
                  "render_kernel", "scale", "gamma_correct"]
 PART2_SYMBOLS = ["vp_last_error", "vp_version", "vp_device_count", "vp_set_device", "vp_set_stream", "vp_get_stream", "vp_synchronize",
                  "vp_set_estimator", "vp_set_rng", "vp_set_envmap_sampling", "vp_get_env_tables", "vp_set_lookahead", "vp_set_tracking", "vp_set_bound_brick", "vp_set_shard", "vp_render_frames",
-                 "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity", "vp_get_pixel_table", "vp_get_null_collision_table",
-                 "vp_julia_voxelize", "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_test_hg", "vp_test_intersect_box",
+                 "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity", "vp_get_pixel_table", "vp_get_null_collision_table", "vp_get_sun_clip_table", "vp_render_class_time_ms", "vp_prepare", "vp_get_pixel_lists",
+                 "vp_julia_voxelize", "vp_cloud_voxelize", "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_test_hg", "vp_test_intersect_box",
                  "vp_test_eval_envmap", "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_current", "vp_ctx_get_current", "vp_ctx_device",
                  "vp_accumulate", "vp_tile_owner", "vp_malloc", "vp_free", "vp_memset",
                  "vp_upload", "vp_download"]
@@ -90,7 +90,12 @@ def lib():
         L.vp_get_opacity.argtypes = [C.c_void_p, C.c_size_t]
         L.vp_get_pixel_table.argtypes = [C.POINTER(Param), C.c_void_p, C.c_size_t]
         L.vp_get_null_collision_table.argtypes = [C.POINTER(Param), C.c_void_p, C.c_size_t]
+        L.vp_get_sun_clip_table.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_float)]
+        L.vp_render_class_time_ms.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_int]
+        L.vp_prepare.argtypes = [C.POINTER(Param)]
+        L.vp_get_pixel_lists.argtypes = [C.POINTER(Param), C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
         L.vp_julia_voxelize.argtypes = [C.c_int, C.c_void_p]
+        L.vp_cloud_voxelize.argtypes = [C.c_int, C.c_uint32, C.c_void_p]
         L.vp_test_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.vp_test_rng.argtypes = [C.c_int] + [C.c_uint32] * 5 + [C.c_int, C.c_void_p]
         L.vp_test_sample_density.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -306,6 +311,31 @@ def render_time_ms(reset=True):
     return t.value, n.value
 
 
+def render_class_time_ms(reset=True):
+    """({"general": ms, "light": ms, "misses_box": ms}, {class: pixels}): kernel time per pixel class since the last reset"""
+    ms = (C.c_double * 3)()
+    px = (C.c_uint32 * 3)()
+    _chk(lib().vp_render_class_time_ms(ms, px, int(reset)))
+    names = ("general", "light", "misses_box")
+    return dict(zip(names, ms[:])), dict(zip(names, px[:]))
+
+
+def prepare(P):
+    """build the per-camera tables, pixel lists and sun table of the current state now (vp_prepare)"""
+    _chk(lib().vp_prepare(C.byref(P)))
+
+
+def pixel_lists(P):
+    """(general, light, misses_box): uint32 arrays of y << 16 | x, the pixel lists of the current shard / camera (test hook)"""
+    cnt = (C.c_uint32 * 3)()
+    _chk(lib().vp_get_pixel_lists(C.byref(P), None, 0, cnt))
+    n = sum(cnt[:])
+    out = np.empty(max(n, 1), np.uint32)
+    _chk(lib().vp_get_pixel_lists(C.byref(P), _p(out), n, cnt))
+    a, b = cnt[0], cnt[0] + cnt[1]
+    return out[:a], out[a:b], out[b:n]
+
+
 def bound_table(quantized=True):
     bnx, bny, bnz, brick, radius = (C.c_int() for _ in range(5))
     _chk(lib().vp_get_bound_table(None, 0, bnx, bny, bnz, brick, radius))
@@ -314,8 +344,18 @@ def bound_table(quantized=True):
     return out, brick.value, radius.value
 
 
+def sun_clip_table(shape):
+    """(uint16[nz, ny, nx], step): per cell, the distance in units of `step` beyond which a ray from anywhere in the cell toward
+    the sun meets empty cells only; 0xffff = unknown (counter-based streams; include/volpath.h vp_get_sun_clip_table)"""
+    out = np.empty(shape, np.uint16)
+    step = C.c_float()
+    _chk(lib().vp_get_sun_clip_table(_p(out), out.size, C.byref(step)))
+    return out, step.value
+
+
 def pixel_table(P):
-    """(H, W, 8) float32: crawl end xyz, packed counts (view as uint32), certified-empty distance, 3 unused"""
+    """(H, W, 8) float32: crawl end xyz, packed counts (view as uint32), certified-empty distance, pixel class (0 general,
+    1 the whole chord is certified empty: light kernel, 2 the camera ray misses the box), 2 unused"""
     out = np.empty((P.height, P.width, 8), np.float32)
     _chk(lib().vp_get_pixel_table(C.byref(P), _p(out), out.size))
     return out
@@ -418,6 +458,13 @@ def julia_volume(n):
     """FractalJuliaSet (kernel.cu:84-140) voxelised on the GPU -> uint8 [k][j][i]."""
     out = np.empty((n, n, n), np.uint8)
     _chk(lib().vp_julia_voxelize(n, _p(out)))
+    return out
+
+
+def cloud_volume(n, seed=1):
+    """the flagged synthetic cloud (vp_cloud_voxelize) voxelised on the GPU -> float32 [k][j][i] in [0,1]"""
+    out = np.empty((n, n, n), np.float32)
+    _chk(lib().vp_cloud_voxelize(n, seed, _p(out)))
     return out
 
 

@@ -5,8 +5,11 @@ sun/sky) and hands them to the HIP library through the reference's entry points.
 """
 import numpy as np
 
-from . import (EST_DECOMP, EST_GLOBAL, RNG_PHILOX, RNG_SAMPLERH, init_envmap, init_volume, julia_volume, make_param,
-               mat, precompute_opacity, set_camera, set_estimator, set_rng, set_shard, set_sun)
+import os
+import tempfile
+
+from . import (DEFAULT_CAMERA, EST_DECOMP, EST_GLOBAL, RNG_PHILOX, RNG_SAMPLERH, cloud_volume, init_envmap, init_volume,
+               julia_volume, make_param, mat, precompute_opacity, set_camera, set_estimator, set_rng, set_shard, set_sun)
 
 # SURVEY.md section 4 anchors for setup_sunsky(0.5, 0.2) (host.cpp:1388-1390)
 DEFAULT_SUN_DIR = (-0.0, 0.951057, -0.309017)
@@ -28,7 +31,48 @@ WORKLOADS = {
                 name="STANDIN_julia512_1280x720_chromatic_decomp_brick16"),
     "c3ref": dict(n=256, width=800, height=600, est=EST_DECOMP, brick=1, chromatic=False,
                   name="julia256_800x600_decomp_refbounds"),
+    # The same shape with a volume that FILLS THE FRAME, as a cloud does (the Julia stand-in above keeps that scene's 88 % of
+    # pixels whose ray never meets the medium): a FLAGGED SYNTHETIC cloud (vp_cloud_voxelize: thresholded fBm value noise with a
+    # soft edge, float densities in [0,1] -- not binary, so local minima / maxima differ and the control component is active),
+    # generated as float, written with dump_dense_volume and read back through loadBinaryFile + its quantiser exactly as a
+    # converted .vdb would be (vdbloader/load_vdb.cpp:52-69 -> host.cpp:915-1013); camera 2 units from the centre looking at it,
+    # so every camera ray enters the box.
+    "c4f": dict(n=512, width=1280, height=720, est=EST_DECOMP, brick=16, chromatic=True, volume="cloud", seed=1,
+                camera_pose=((2.0, 0.35, 0.25), (-0.97, -0.17, -0.12), (0.0, 1.0, 0.0)),
+                name="STANDIN_fbmcloud512_framefilling_1280x720_chromatic_decomp_brick16"),
 }
+
+
+def camera_of(cfg):
+    """row-major 3x4 camera-to-world of a workload (H4: lookAt -> inverse -> transpose through the C++ host library)"""
+    if "camera_pose" not in cfg:
+        return tuple(DEFAULT_CAMERA)
+    from . import host
+    pos, fwd, up = cfg["camera_pose"]
+    return tuple(float(v) for v in host.camera_matrix(pos, fwd, up))
+
+
+def host_volume(workload, oracle=None):
+    """The uchar grid of a workload in host memory, [k][j][i].  Julia: voxelised on the GPU (or by `oracle`, the CPU-baseline leg
+    of bench.py, which must not need a GPU library call for it); cloud: generated as float, dumped as a dense .bin and read back
+    through loadBinaryFile with its quantiser -- the ingest path a converted .vdb takes."""
+    cfg = WORKLOADS[workload]
+    if cfg.get("volume", "julia") == "julia":
+        return oracle.julia(cfg["n"]) if oracle is not None else julia_volume(cfg["n"])
+    from . import host
+    vol = oracle.cloud(cfg["n"], cfg["seed"]) if oracle is not None else cloud_volume(cfg["n"], cfg["seed"])
+    fd, path = tempfile.mkstemp(suffix=".bin", prefix="volpath_cloud_")
+    os.close(fd)
+    try:
+        if not host.dump_dense(path, vol):
+            raise RuntimeError("dump_dense_volume failed")
+        del vol
+        grid = host.load_binary(path, quantized=True)
+        if grid is None:
+            raise RuntimeError("loadBinaryFile failed")
+    finally:
+        os.unlink(path)
+    return grid
 
 
 def gradient_sky(w=1024, h=512):
@@ -55,12 +99,13 @@ def setup(workload, rng_mode=RNG_PHILOX, key=(0x9E3779B9, 0x85EBCA6B), rank=0, w
           last_frame=0):
     """Upload one BASELINE configuration; returns (Param, info)."""
     cfg = WORKLOADS[workload]
-    grid = julia_volume(cfg["n"])
+    grid = host_volume(workload)
     init_volume(grid, brick=cfg["brick"], linear=True)  # host.cpp:1342-1344
     env, sun_dir, sun_power = sunsky if sunsky is not None else default_sunsky()
     init_envmap(env)
     set_sun(sun_dir, sun_power)
-    set_camera()
+    cam = camera_of(cfg)
+    set_camera(cam)
     set_estimator(cfg["est"])
     set_rng(rng_mode, key)
     set_shard(rank, world)
@@ -69,4 +114,10 @@ def setup(workload, rng_mode=RNG_PHILOX, key=(0x9E3779B9, 0x85EBCA6B), rank=0, w
         mat(P, *PRESET1)
     if cfg["est"] == EST_DECOMP and opacity and last_frame > 10:
         precompute_opacity(sun_dir)  # host.cpp:336-343
-    return P, dict(cfg, occupancy=float(grid.mean() / 255.0), sunsky=(env, sun_dir, sun_power))
+    info = dict(cfg, occupancy=float(grid.mean() / 255.0), sunsky=(env, sun_dir, sun_power), camera=cam)
+    if cfg.get("volume", "julia") == "cloud":
+        info["volume"] = f"{cfg['n']}^3 uchar, FLAGGED SYNTHETIC cloud (vp_cloud_voxelize seed {cfg['seed']}) through dump_dense_volume -> loadBinaryFile"
+        info["note"] = "synthetic stand-in for the WDAS cloud (no data set, no OpenVDB in the image); frame-filling"
+    elif workload == "c4s":
+        info["note"] = "synthetic stand-in for the WDAS cloud (Julia set at 512^3: keeps that scene's mostly-empty frame; see c4f)"
+    return P, info

@@ -107,7 +107,8 @@ enum { VP_EST_GLOBAL = 0, /* __d_render, kernel.cu:1285-1591: global majorant (B
        VP_EST_BOUNDED = 2 /* __d_render_bounded, kernel.cu:1667-1952: local majorant, no control component,
                              800 tracked segments at most, heat = segments * 0.001, never reads the opacity volume */ };
 enum { VP_RNG_SAMPLERH = 0, /* src/sampler.h bit-compatible streams (parity mode) */
-       VP_RNG_PHILOX   = 1, /* Philox2x32-10, counter = (draw/2, x<<16|y), key = (frame ^ key0) + key1 */
+       VP_RNG_PHILOX   = 1, /* Philox2x32-10, counter = (draw/2, x<<16|y), key = (frame ^ key0) + key1; shadow rays draw from
+                               sub-streams: counter word 0 = 0x80000000 + ((2 * depth + ray) << 20) + step */
        VP_RNG_PHILOX7  = 2  /* Philox2x32-7 (the fewest rounds Random123 documents as Crush-resistant), same counter / key;
                                built for the shipped configuration (spectral tracking, passive environment) */ };
 
@@ -190,14 +191,33 @@ int vp_read_counters(vp_counters* out, int reset); /* synchronises */
  * their events have completed, so a host that never asks does not accumulate events. */
 int vp_render_time_ms(double* total_ms, int* launches, int reset);
 
+/* The same per pixel class: ms[0] the general kernel (pixels whose camera ray can meet the medium), ms[1] the
+ * light kernel (the whole chord is certified empty), ms[2] the fill of the pixels whose ray misses the box; HIP events around each
+ * kernel on the stream it runs on (the first two run side by side, so the times overlap).  pixels[] = the pixels of each class
+ * in the current lists of this context.  Either pointer may be NULL.  Synchronises. */
+int vp_render_class_time_ms(double ms[3], unsigned pixels[3], int reset);
+/* Builds everything a render of this Param would build first -- the per-pixel tables of the current camera, the pixel lists
+ * of the shard, the sun table -- and waits for it.  A host that moves the camera may call it to take that work out of its
+ * first frame; bench.py times it (per_camera_setup_ms).  Not needed for correctness: render_kernel does the same on demand. */
+int vp_prepare(const Param* p);
+/* test hook: the pixel lists of this context for p (after vp_prepare): dst[0 .. counts[0]) the general pixels, then counts[1]
+ * light ones, then counts[2] whose camera ray misses the box, each y << 16 | x in tile order; dst may be NULL to ask for the counts */
+int vp_get_pixel_lists(const Param* p, uint32_t* dst, size_t count, unsigned counts[3]);
+
 /* the derived tables, for tests: bound table dims/brick and a device->host copy */
 int vp_get_bound_table(void* dst, size_t bytes, int* bnx, int* bny, int* bnz, int* brick, int* radius);
 int vp_get_opacity(float* dst, size_t count);
 /* the per-pixel table of the current estimator / camera / volume for a width x height image, 8 floats per pixel:
  * [0..2] where the restart crawl in front of the volume ends (local-majorant estimators; the camera origin otherwise),
  * [3] its segment and draw counts (bits: segments | draws << 16), [4] the distance from there up to which the camera ray is
- * certified to meet only empty cells, [5..7] unused.  Test hook for the certificates. */
+ * certified to meet only empty cells, [5] the pixel class (0 general; 1 the whole chord is certified empty: light kernel; 2 the
+ * camera ray misses the box: one constant per pixel), [6..7] unused.  Test hook for the certificates. */
 int vp_get_pixel_table(const Param* p, float* dst, size_t count);
+/* Counter-based streams (VP_RNG_PHILOX / VP_RNG_PHILOX7): a shadow ray draws from a sub-stream of its own, so the path's later
+ * draws do not depend on the number of steps it takes, and a sun shadow ray ends once it has only empty cells in front of it.
+ * dst[cell] (x fastest, count >= nx*ny*nz) = that distance from anywhere in the cell, in units of *step (world units), or
+ * 0xffff = unknown (the ray is walked to its end).  Test hook for the certificate; VP_NO_SUN_CLIP=1 switches the table off. */
+int vp_get_sun_clip_table(unsigned short* dst, size_t count, float* step);
 /* dst[n] = throughput of an unscattered path of the global-majorant estimator after n null collisions in empty space, n < count
  * (spectral tracking: the weight of such a collision is 1 only up to rounding; the light kernel looks the product up by n).
  * Test hook: the sequence is three float32 operations per step and can be restated anywhere. */
@@ -219,6 +239,11 @@ int vp_test_eval_envmap(const float* dir_xyz, float* rgb, int n);
  * texel centres over [-1,1]^3 to an n^3 uchar grid (0 / 255), x fastest; written to HOST memory so it
  * can be handed to init_cuda like any other volume. */
 int vp_julia_voxelize(int n, unsigned char* host_out);
+/* A FLAGGED SYNTHETIC stand-in for the WDAS cloud of BASELINE configs 4/5 (neither the data set nor OpenVDB exists in the build
+ * image): five octaves of hashed-lattice value noise, thresholded, with a soft spherical edge, voxelised at texel centres over
+ * [-1,1]^3 to n^3 float densities in [0,1] (not binary), x fastest, written to HOST memory -- to be dumped with dump_dense_volume
+ * and read back with loadBinaryFile like a converted .vdb.  Deterministic in (n, seed); the oracle restates it bit for bit. */
+int vp_cloud_voxelize(int n, uint32_t seed, float* host_out);
 
 /* raw device memory helpers */
 void* vp_malloc(size_t bytes);

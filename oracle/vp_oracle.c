@@ -90,6 +90,7 @@ typedef struct
     uint32_t ctr[2], key;    /* philox: ctr = (draw pair index, x<<16|y), key = (frame ^ seed0) + seed1 */
     uint32_t buf[2];
     uint32_t n; /* philox: pairs so far */
+    uint32_t n_saved; /* philox: position of the path's own stream while a shadow ray draws from its sub-stream */
     uint64_t* draws;
 } rng_t;
 
@@ -151,6 +152,25 @@ static inline float rng_draw(rng_t* r, int second)
 #define rng_next_a(r) rng_draw((r), 0)
 #define rng_next_b(r) rng_draw((r), 1)
 
+/* Counter-based streams only: a shadow ray (Tr_spectral / Tr, kernel.cu:754-808 / :712-751) draws from a SUB-STREAM of its
+ * own -- pair indices 0x80000000 + (id << 20) + 0, 1, 2, ... with id = 2 * (scatter depth) + (0 sun ray, 1 the environment
+ * ray of the one-sample MIS) -- and the path's own stream goes on afterwards where it stood before the shadow ray.  The
+ * draws the path makes after a light estimate then do not depend on how many steps that estimate took, so an
+ * implementation may stop a shadow ray as soon as nothing can change its result any more (the HIP path does: a ray that
+ * has reached cells which are empty all the way out).  sampler.h mode is the reference's sequential
+ * stream: nothing changes there. */
+static inline void rng_enter_shadow(rng_t* r, uint32_t id)
+{
+    if (r->mode == VPO_RNG_SAMPLERH) return;
+    r->n_saved = r->n;
+    r->n       = 0x80000000u + (id << 20);
+}
+static inline void rng_leave_shadow(rng_t* r)
+{
+    if (r->mode == VPO_RNG_SAMPLERH) return;
+    r->n = r->n_saved;
+}
+
 void vpo_rng_stream(int mode, uint32_t x, uint32_t y, uint32_t frame, uint32_t k0, uint32_t k1, int n, float* out)
 {
     vpo_scene S;
@@ -195,6 +215,57 @@ void vpo_julia_voxelize(int n, uint8_t* grid)
                            ((float)k + 0.5f) / fn * 2.0f - 1.0f);
                 grid[(size_t)i + (size_t)n * ((size_t)j + (size_t)n * (size_t)k)] =
                     (uint8_t)(255.0f * julia_density(p));
+            }
+}
+
+/* The FLAGGED SYNTHETIC cloud of the 512^3 workloads (include/volpath.h vp_cloud_voxelize; SURVEY.md section 8(d) asks for
+ * such a stand-in where the WDAS data does not exist): restated operation by operation from its definition -- five octaves of
+ * value noise on hashed lattices, thresholded, soft spherical edge -- in binary32 without contraction. */
+static inline float cloud_lattice(int ix, int iy, int iz, uint32_t seed)
+{
+    uint32_t h = vpo_hash(((uint32_t)ix * 73856093u) ^ ((uint32_t)iy * 19349663u) ^ ((uint32_t)iz * 83492791u) ^ seed);
+    return (float)(h & 0xffffffu) * (1.0f / 16777216.0f);
+}
+static float cloud_noise(float x, float y, float z, uint32_t seed)
+{
+    float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+    int   ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    float tx = x - fx, ty = y - fy, tz = z - fz;
+    tx = (tx * tx) * (3.0f - 2.0f * tx);
+    ty = (ty * ty) * (3.0f - 2.0f * ty);
+    tz = (tz * tz) * (3.0f - 2.0f * tz);
+    float c000 = cloud_lattice(ix, iy, iz, seed), c100 = cloud_lattice(ix + 1, iy, iz, seed);
+    float c010 = cloud_lattice(ix, iy + 1, iz, seed), c110 = cloud_lattice(ix + 1, iy + 1, iz, seed);
+    float c001 = cloud_lattice(ix, iy, iz + 1, seed), c101 = cloud_lattice(ix + 1, iy, iz + 1, seed);
+    float c011 = cloud_lattice(ix, iy + 1, iz + 1, seed), c111 = cloud_lattice(ix + 1, iy + 1, iz + 1, seed);
+    float x00 = c000 + (c100 - c000) * tx, x10 = c010 + (c110 - c010) * tx;
+    float x01 = c001 + (c101 - c001) * tx, x11 = c011 + (c111 - c011) * tx;
+    float y0 = x00 + (x10 - x00) * ty, y1 = x01 + (x11 - x01) * ty;
+    return y0 + (y1 - y0) * tz;
+}
+void vpo_cloud_voxelize(int n, uint32_t seed, float* grid)
+{
+    float fn = (float)n;
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < n; k++)
+        for (int j = 0; j < n; j++)
+            for (int i = 0; i < n; i++)
+            {
+                float px = ((float)i + 0.5f) / fn * 2.0f - 1.0f, py = ((float)j + 0.5f) / fn * 2.0f - 1.0f,
+                      pz = ((float)k + 0.5f) / fn * 2.0f - 1.0f;
+                float sum = 0.0f, amp = 0.5f, freq = 2.0f;
+                for (int o = 0; o < 5; o++)
+                {
+                    sum  = sum + amp * cloud_noise(px * freq + 17.0f, py * freq + 17.0f, pz * freq + 17.0f,
+                                                   seed + (uint32_t)o * 0x9E3779B9u);
+                    amp  = amp * 0.5f;
+                    freq = freq * 2.0f;
+                }
+                float v = (sum * (1.0f / 0.96875f) - 0.44f) * 3.0f;
+                v = fminf(fmaxf(v, 0.0f), 1.0f);
+                float r    = sqrtf(px * px + py * py + pz * pz);
+                float edge = fminf(fmaxf((1.2f - r) * (1.0f / 0.4f), 0.0f), 1.0f);
+                grid[(size_t)i + (size_t)n * ((size_t)j + (size_t)n * (size_t)k)] = v * edge;
             }
 }
 
@@ -637,7 +708,7 @@ static int intersect_super_volume(const vpo_scene* S, f3 o, f3 d, f3 bmin, f3 bm
 /* ------------------------------------------------ shadow transmittance (A7) -- */
 /* Tr_spectral kernel.cu:754-808: shared free-flight sample, per-channel termination flags */
 static f3 tr_spectral(const vpo_scene* S, f3 bmin, f3 bmax, f3 start, f3 end, float inv_sigma, float density,
-                      f3 sigma_t_spectral, rng_t* rng, vpo_counters* C)
+                      f3 sigma_t_spectral, rng_t* rng, uint32_t shadow_id, vpo_counters* C)
 {
     f3    o = start;
     f3    d = normalize3(sub3(end, start));
@@ -648,6 +719,7 @@ static f3 tr_spectral(const vpo_scene* S, f3 bmin, f3 bmax, f3 start, f3 end, fl
     float max_t = fminf(t_far, length3(sub3(start, end)));
     float dist  = t_near;
     int   xterm = 0, yterm = 0, zterm = 0;
+    rng_enter_shadow(rng, shadow_id);
     for (;;)
     {
         dist += -vpo_logf(rng_next_a(rng)) * inv_sigma;
@@ -659,6 +731,7 @@ static f3 tr_spectral(const vpo_scene* S, f3 bmin, f3 bmax, f3 start, f3 end, fl
         if (!yterm && e < sigma_t_spectral.y * den * inv_sigma) yterm = 1;
         if (!zterm && e < sigma_t_spectral.z * den * inv_sigma) zterm = 1;
     }
+    rng_leave_shadow(rng);
     return mk3((float)(1 - xterm), (float)(1 - yterm), (float)(1 - zterm));
 }
 
@@ -673,7 +746,7 @@ uint64_t vpo_debug_mis_zero_pdf(void) { return __atomic_load_n(&g_mis_zero_pdf, 
  * scattered-direction update, i.e. from the old ray origin in the old direction (with the scatter already counted). */
 static int mis_envmap(const vpo_scene* S, rng_t* rng, vpo_counters* C, const frame_t* frame, float g, f3 pos,
                       f3 throughput, float inv_sigma, float density_prime, f3 sigma_t_spectral, f3 boxMin,
-                      f3 boxMax, f3* radiance)
+                      f3 boxMax, f3* radiance, uint32_t depth)
 {
     const float P_phase  = 0.5f;
     const float P_envmap = 1.0f - P_phase;
@@ -688,7 +761,7 @@ static int mis_envmap(const vpo_scene* S, rng_t* rng, vpo_counters* C, const fra
         float a_ = pdf_brdf * P_phase, b_ = pdf_env_virtual * P_envmap;
         float weight = a_ / (a_ + b_) / P_phase;
         f3 a = tr_spectral(S, boxMin, boxMax, pos, muls(brdf_dir, 1e10f), inv_sigma, density_prime, sigma_t_spectral,
-                           rng, C);
+                           rng, 2u * depth + 1u, C);
         *radiance = add3(*radiance, mul3(envc, mul3(muls(throughput, weight), a)));
     }
     else
@@ -707,7 +780,7 @@ static int mis_envmap(const vpo_scene* S, rng_t* rng, vpo_counters* C, const fra
         float a_ = pdf_env * P_envmap, b_ = pdf_brdf_virtual * P_phase;
         float weight = a_ / (a_ + b_) / P_envmap;
         f3 a = tr_spectral(S, boxMin, boxMax, pos, muls(envmap_dir, 1e10f), inv_sigma, density_prime, sigma_t_spectral,
-                           rng, C);
+                           rng, 2u * depth + 1u, C);
         float ph = vpo_hg_eval(g, dot3(frame->n, envmap_dir));
         f3    t  = muls(divs(muls(throughput, ph), pdf_env), weight);
         *radiance = add3(*radiance, mul3(envc, mul3(t, a)));
@@ -874,11 +947,11 @@ static void sample_decomp(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
             }
             else
                 a = tr_spectral(S, boxMin, boxMax, pos, muls(sun_dir, 1e10f), inv_sigma2, density_prime2,
-                                sigma_t_spectral, &rng, C);
+                                sigma_t_spectral, &rng, 2u * (uint32_t)num_scatters, C);
             /* sun_light_power * (throughput * phase * a) */
             radiance = add3(radiance, mul3(sun_power, mul3(muls(throughput, ph), a)));
             if (S->env_mis && mis_envmap(S, &rng, C, &frame, phase_g, pos, throughput, inv_sigma2, density_prime2,
-                                         sigma_t_spectral, boxMin, boxMax, &radiance))
+                                         sigma_t_spectral, boxMin, boxMax, &radiance, (uint32_t)num_scatters))
                 continue; /* :2266 */
         }
 
@@ -993,10 +1066,10 @@ static void sample_bounded(const vpo_scene* S, const vpo_param* P, uint32_t x, u
             float inv_sigma2     = 1.0f / sigma_t_prime2;
             float ph = vpo_hg_eval(g, dot3(frame.n, sun_dir));
             f3    a  = tr_spectral(S, boxMin, boxMax, pos, muls(sun_dir, 1e10f), inv_sigma2, density_prime2,
-                                   sigma_t_spectral, &rng, C);
+                                   sigma_t_spectral, &rng, 2u * (uint32_t)num_scatters, C);
             radiance = add3(radiance, mul3(sun_power, mul3(muls(throughput, ph), a)));
             if (S->env_mis && mis_envmap(S, &rng, C, &frame, g, pos, throughput, inv_sigma2, density_prime2,
-                                         sigma_t_spectral, boxMin, boxMax, &radiance))
+                                         sigma_t_spectral, boxMin, boxMax, &radiance, (uint32_t)num_scatters))
                 continue; /* :1900; the loop index still advances */
         }
         float r0 = rng_next_a(&rng);
@@ -1098,11 +1171,11 @@ static void sample_global(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
             float sigma_t_prime2 = max_sigma_t * density_prime2;
             float inv_sigma2     = 1.0f / sigma_t_prime2;
             f3 a = tr_spectral(S, boxMin, boxMax, pos, muls(sun_dir, 1e10f), inv_sigma2, density_prime2,
-                               sigma_t_spectral, &rng, C);
+                               sigma_t_spectral, &rng, 2u * (uint32_t)i, C);
             float ph = vpo_hg_eval(g, dot3(frame.n, sun_dir));
             radiance = add3(radiance, mul3(sun_power, mul3(muls(throughput, ph), a)));
             if (S->env_mis && mis_envmap(S, &rng, C, &frame, g, pos, throughput, inv_sigma2, density_prime2,
-                                         sigma_t_spectral, boxMin, boxMax, &radiance))
+                                         sigma_t_spectral, boxMin, boxMax, &radiance, (uint32_t)i))
                 continue; /* :1539; the depth index still advances */
         }
         float r0 = rng_next_a(&rng);
@@ -1121,7 +1194,7 @@ static void sample_global(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
 /* -------------------------- scalar tracking: SPECTRAL_TRACKING 0 / MULTI_CHANNEL 1 -- */
 /* Tr kernel.cu:712-751: the scalar shadow ray; stops AT its first collision (no further draw) */
 static float tr_scalar(const vpo_scene* S, f3 bmin, f3 bmax, f3 start, f3 end, float inv_sigma, float density,
-                       rng_t* rng, vpo_counters* C)
+                       rng_t* rng, uint32_t shadow_id, vpo_counters* C)
 {
     f3    o = start;
     f3    d = normalize3(sub3(end, start));
@@ -1130,6 +1203,7 @@ static float tr_scalar(const vpo_scene* S, f3 bmin, f3 bmax, f3 start, f3 end, f
     if (t_near < 0.0f) t_near = 0.0f;
     float max_t = fminf(t_far, length3(sub3(start, end)));
     float dist  = t_near;
+    rng_enter_shadow(rng, shadow_id);
     for (;;)
     {
         dist += -vpo_logf(rng_next_a(rng)) * inv_sigma;
@@ -1137,6 +1211,7 @@ static float tr_scalar(const vpo_scene* S, f3 bmin, f3 bmax, f3 start, f3 end, f
         f3 pos = add3(o, muls(d, dist));
         if (rng_next_b(rng) < vol_sigma_t(S, pos, density, C) * inv_sigma) break;
     }
+    rng_leave_shadow(rng);
     return (float)(dist >= max_t);
 }
 
@@ -1239,7 +1314,8 @@ static void sample_scalar(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
                 a = vpo_expf(-sigma_t_prime2 * sample_volume(S, NULL, S->opacity, 1, pos)); /* :2190 */
             }
             else
-                a = tr_scalar(S, boxMin, boxMax, pos, muls(sun_dir, 1e10f), inv_sigma2, sigma_t_prime2, &rng, C);
+                a = tr_scalar(S, boxMin, boxMax, pos, muls(sun_dir, 1e10f), inv_sigma2, sigma_t_prime2, &rng,
+                              2u * (uint32_t)(est == VPO_EST_GLOBAL ? i : num_scatters), C);
             radiance = add3(radiance, mul3(sun_power, muls(muls(throughput, ph), a)));
         }
         float r0 = rng_next_a(&rng);

@@ -97,6 +97,7 @@ void     vpo_rng_stream(int mode, uint32_t x, uint32_t y, uint32_t frame, uint32
 void     vpo_philox2x32_10(const uint32_t ctr[2], uint32_t key, uint32_t out[2]);
 void     vpo_philox2x32_7(const uint32_t ctr[2], uint32_t key, uint32_t out[2]);
 void     vpo_julia_voxelize(int n, uint8_t* grid);
+void     vpo_cloud_voxelize(int n, uint32_t seed, float* grid); /* the flagged synthetic cloud of the 512^3 workloads */
 int      vpo_bound_radius(int nx, float search_radius);
 void     vpo_bounds_u8(const uint8_t* grid, int nx, int ny, int nz, int radius, int brick, uint8_t* out);
 void     vpo_bounds_f32(const float* grid, int nx, int ny, int nz, int radius, int brick, float* out);

@@ -4,7 +4,8 @@
 
 Sources, by authority:
   ref_anchors.json   values recorded FROM THE REFERENCE (SURVEY.md section 4 / section 6 probes) and the
-                     published Random123 Philox known-answer vectors -- typed in, not computed here.
+                     published Random123 Philox known-answer vectors -- typed in and kept by hand; this script never
+                     writes it.
   hosek_ref.npz      outputs of the reference's own Hosek sky sources (oracle/_ref/libhosek_ref.so,
                      built by oracle/Makefile from /root/reference/src/sunsky/hosek where they lie).
   oracle_*.npz       outputs of the CPU oracle (regression vectors for the GPU path; oracle-made).
@@ -21,28 +22,6 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
 import scenes  # noqa: E402
-
-
-def ref_anchors():
-    a = {
-        "source": "SURVEY.md section 4 (values captured from the reference's sampler.h / sky code) and section 6",
-        "hash": {"0": 0xc0a9496a, "1": 0x27922c9d, str(0x00030005): 0xb5ac5390},
-        "cudarng": {"3,5,7": [0.310083151, 0.486427426, 0.107821465, 0.729314804],
-                    "0,0,0": [0.484132648, 0.372826576, 0.202771664, 0.32959044]},
-        "default_sun_dir": [-0.0, 0.951057, -0.309017],
-        "default_sun_color_x0.02": [51797.34, 42480.11, 32578.49],
-        "default_env0": [0.087455, 0.115298, 0.204543],
-        "julia_occupancy": 0.0265,
-        "work_counters_julia256_800x600": {"density_lookups": 97.6, "bound_lookups": 51.3, "env_lookups": 1.0,
-                                           "zero_scatter_pixel_fraction": 0.88, "p90_scatters": 13.9,
-                                           "p99_scatters": 48.9},
-        "bound_radius": {"32": 1, "64": 2, "128": 4, "256": 7, "512": 13},
-        "philox2x32_10_random123_kat": [
-            {"ctr": [0, 0], "key": 0, "out": [0xff1dae59, 0x6cd10df2]},
-            {"ctr": [0xffffffff, 0xffffffff], "key": 0xffffffff, "out": [0x2c3f628b, 0xab4fd7ad]},
-            {"ctr": [0x243f6a88, 0x85a308d3], "key": 0x13198a2e, "out": [0xdd7ce038, 0xf62a4c12]}],
-    }
-    json.dump(a, open(os.path.join(HERE, "ref_anchors.json"), "w"), indent=1)
 
 
 def hosek_ref():
@@ -119,7 +98,6 @@ def oracle_renders():
 
 if __name__ == "__main__":
     O.build()
-    ref_anchors()
     hosek_ref()
     oracle_renders()
     print("golden fixtures written to", HERE)

@@ -90,6 +90,12 @@ def julia(n):
     return g
 
 
+def cloud(n, seed=1):
+    g = np.empty((n, n, n), np.float32)  # [k][j][i], x fastest
+    lib().vpo_cloud_voxelize(C.c_int(n), C.c_uint32(seed), _p(g))
+    return g
+
+
 def bound_radius(nx, search_radius=0.05):
     return lib().vpo_bound_radius(nx, search_radius)
 

@@ -361,3 +361,89 @@ def test_torch_rccl_backend_runs_a_one_rank_reduce():
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "REDUCE True" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,world", [(160, 120, 1), (67, 45, 3), (1280, 720, 8), (9, 7, 4), (800, 600, 2)])
+def test_pixel_lists_are_the_stable_partition_of_the_tile_order(vp, W, H, world):
+    """The pixel lists are built on the GPU (pixlist_*_k) since round 3.  Restated here in numpy from their definition: the
+    rank's pixels tile by tile (row-major 8x8 tiles owned per vp_tile_owner, row-major pixels within a tile, partial edge tiles
+    clipped), stably partitioned by the class in the pixel table.  Every rank, ragged sizes, more ranks than tiles in a row."""
+    import scenes
+    grid = vp.julia_volume(32)
+    vp.init_volume(grid, brick=1, linear=True)
+    vp.init_envmap(scenes.synthetic_env())
+    vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+    vp.set_camera()
+    vp.set_estimator(vp.EST_GLOBAL)
+    vp.set_tracking(0)
+    vp.set_rng(vp.RNG_PHILOX7, (1, 2))
+    P = vp.make_param(W, H)
+    seen = np.zeros((H, W), int)
+    try:
+        for rank in range(world):
+            vp.set_shard(rank, world)
+            cls = vp.pixel_table(P)[..., 5].astype(int)
+            want = [[], [], []]
+            for ty in range((H + 7) // 8):
+                for tx in range((W + 7) // 8):
+                    if vp.tile_owner(tx, ty, world) != rank:
+                        continue
+                    for y in range(ty * 8, min(ty * 8 + 8, H)):
+                        for x in range(tx * 8, min(tx * 8 + 8, W)):
+                            want[cls[y, x]].append(y << 16 | x)
+            got = vp.pixel_lists(P)
+            for c in range(3):
+                assert np.array_equal(got[c], np.asarray(want[c], np.uint32)), (rank, c)
+                seen[got[c] >> 16, got[c] & 0xffff] += 1
+        assert np.all(seen == 1)
+    finally:
+        vp.set_shard(0, 1)
+
+
+@pytest.mark.gpu
+def test_cloud_generator_matches_the_oracle_and_survives_the_ingest_path(vp, oracle, tmp_path):
+    """The flagged synthetic cloud of workload c4f: GPU generator == the oracle's restatement bit for bit; float densities that
+    are not binary; through dump_dense_volume -> loadBinaryFile + quantiser it arrives as the quantised grid."""
+    from volpath import host
+    for n, seed in ((40, 1), (33, 7)):
+        g = vp.cloud_volume(n, seed)
+        assert np.array_equal(g, oracle.cloud(n, seed))
+        assert g.min() == 0.0 and 0.9 < g.max() <= 1.0
+        frac = ((g > 0.02) & (g < 0.98)).mean()
+        assert frac > 0.2, "the cloud is meant to have soft values, not a binary mask"
+    path = str(tmp_path / "cloud.bin")
+    assert host.dump_dense(path, g)
+    q = host.load_binary(path, quantized=True)
+    assert q.shape == g.shape and np.array_equal(q, host.quantize(g))
+
+
+@pytest.mark.gpu
+def test_class_times_and_prepare(vp):
+    """vp_prepare builds the per-camera tables without rendering; vp_render_class_time_ms reports one event pair per kernel of a
+    launch and the pixels of each class."""
+    import scenes
+    grid = vp.julia_volume(64)
+    vp.init_volume(grid, brick=1, linear=True)
+    vp.init_envmap(scenes.synthetic_env())
+    vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+    vp.set_camera()
+    vp.set_estimator(vp.EST_GLOBAL)
+    vp.set_tracking(0)
+    vp.set_shard(0, 1)
+    vp.set_rng(vp.RNG_PHILOX7, (1, 2))
+    W, H = 320, 240
+    P = vp.make_param(W, H)
+    vp.prepare(P)
+    vp.render_class_time_ms(reset=True)
+    buf = vp.DeviceBuffer(W, H)
+    vp.render_frames(buf.ptr, 0, 8, P)
+    vp.synchronize()
+    ms, px = vp.render_class_time_ms(reset=True)
+    buf.free()
+    assert sum(px.values()) == W * H and all(v > 0 for v in px.values())
+    assert all(ms[k] > 0 for k in ms)
+    total, launches = vp.render_time_ms(reset=True)
+    assert launches >= 1 and total >= max(ms.values()) * 0.9
+    ms2, _ = vp.render_class_time_ms(reset=True)
+    assert all(v == 0 for v in ms2.values())

@@ -274,3 +274,28 @@ def test_scale_gamma_and_mat(oracle):
     st = np.array([2.29 + 0.0030, 2.39 + 0.0034, 1.97 + 0.046])
     assert np.allclose(list(P.sigma_t), st / st.max(), rtol=1e-6)
     assert np.allclose(list(P.albedo), np.array([2.29, 2.39, 1.97]) / st, rtol=1e-6)
+
+
+def test_oracle_shadow_rays_draw_from_their_own_substream(oracle):
+    """Counter-based streams (oracle rng_enter_shadow): a shadow ray draws pairs 0x80000000 + (id << 20) + 0, 1, ... and the
+    path's own stream goes on where it stood.  With the sun's power at zero the image is the environment seen by the escaping
+    paths: identical for two sun directions (shadow rays of different lengths) with Philox, different with the reference's
+    sequential sampler.h stream."""
+    import scenes
+    O = oracle
+    grid = O.julia(32)
+    env = scenes.synthetic_env()
+    P = O.default_param(48, 36)
+    for est in (O.EST_GLOBAL, O.EST_DECOMP, O.EST_BOUNDED):
+        same = {}
+        for rng_mode in (O.RNG_PHILOX7, O.RNG_SAMPLERH):
+            imgs = []
+            for sun in ((-0.0, 0.951057, -0.309017), (0.0, 0.6, 0.8)):
+                sc = O.OracleScene(grid, env, sun, (0.0, 0.0, 0.0), estimator=est, rng_mode=rng_mode, seed=(5, 6))
+                acc = None
+                for f in range(3):
+                    acc, cnt = sc.render_frame(P, f, acc)
+                imgs.append(acc)
+            assert imgs[0][..., 3].max() > 0
+            same[rng_mode] = np.array_equal(imgs[0], imgs[1])
+        assert same[O.RNG_PHILOX7] and not same[O.RNG_SAMPLERH]

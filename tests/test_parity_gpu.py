@@ -453,7 +453,7 @@ def test_active_envmap_mis_bit_exact(vp, oracle, est, rng_mode):
         vp.set_envmap_sampling(vp.ENV_PASSIVE)
 
 
-@pytest.mark.parametrize("est,frame", [(0, 48), (0, 1733), (1, 4452), (2, 4452)])
+@pytest.mark.parametrize("est,frame", [(0, 6636), (0, 9355), (1, 10110), (2, 10110)])
 def test_mis_zero_pdf_continue_quirk(vp, oracle, est, frame):
     """kernel.cu:2266 / :1539 / :1900: an environment sample of zero pdf `continue`s the path loop, so the path goes on
     from the OLD origin in the OLD direction.  It takes a random number of exactly 0 on a black first column; the

@@ -456,6 +456,93 @@ def test_pixel_table_certificates_hold_in_float64(vp, est):
     assert (t_left[hit] > 0).mean() > 0.8 and (cls[hit] == 1).mean() > 0.3
 
 
+@pytest.mark.parametrize("sun", [(-0.0, 0.951057, -0.309017), (0.6, -0.3, 0.74), (0.0, 0.0, -1.0)])
+def test_sun_clip_certificate_holds_in_float64(vp, sun):
+    """Counter-based streams end a sun shadow ray where it has only empty cells left (vp_kernels.hip sun_clip_k).  The table is
+    a claim about geometry, checked here in float64 against the raw volume, without the oracle: from random start points in
+    random non-empty cells, every point of the ray toward the sun beyond table[cell] * step lies in a cell whose 2x2x2 texels
+    are all zero.  Also: every non-empty cell has an entry, empty cells are marked unknown, and the table is not vacuous."""
+    import scenes
+    rng = np.random.default_rng(11)
+    n = 48
+    grid = vp.julia_volume(n)
+    vp.init_volume(grid, brick=1, linear=True)
+    vp.init_envmap(scenes.synthetic_env())
+    sun = np.asarray(sun, np.float64) / np.linalg.norm(sun)
+    vp.set_sun(tuple(sun), scenes.DEFAULT_SUN_POWER)
+    vp.set_camera()
+    vp.set_rng(vp.RNG_PHILOX7, (1, 2))
+    table, step = vp.sun_clip_table((n, n, n))
+    assert abs(step - 0.25 * 2.0 / n) < 1e-7
+    g = np.pad(grid, ((0, 1), (0, 1), (0, 1)), mode="edge") != 0
+    cell_nonempty = np.zeros((n, n, n), bool)
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                cell_nonempty |= g[dz:dz + n, dy:dy + n, dx:dx + n]
+    assert np.array_equal(table == 0xffff, ~cell_nonempty)
+    ks, js, is_ = np.nonzero(cell_nonempty)
+    pick = rng.choice(len(ks), 600, replace=False)
+    cell = 2.0 / n
+    checked = 0
+    for k, j, i in zip(ks[pick], js[pick], is_[pick]):
+        # a random point of the cell in continuous cell coordinates xb = p * N - 0.5 (cell 0 also takes xb in [-0.5, 0), the last
+        # cell ends at N - 0.5), as a world position
+        lo = np.array([-0.5 if c == 0 else c for c in (i, j, k)], np.float64)
+        hi = np.array([n - 0.5 if c == n - 1 else c + 1 for c in (i, j, k)], np.float64)
+        xb = lo + (hi - lo) * rng.random(3)
+        p0 = (xb + 0.5) / n * 2.0 - 1.0
+        t0 = float(table[k, j, i]) * step
+        # to the box exit (slab test), sampled at 1/20 cell
+        with np.errstate(divide="ignore"):
+            tt = np.where(sun > 0, (1.0 - p0) / sun, np.where(sun < 0, (-1.0 - p0) / sun, np.inf))
+        t1 = float(tt.min())
+        if t1 <= t0:
+            continue
+        ts = np.arange(t0, t1, cell / 20)
+        q = (p0 + sun * ts[:, None] + 1.0) / 2.0 * n - 0.5
+        idx = np.clip(np.floor(np.maximum(q, 0)).astype(int), 0, n - 1)
+        assert not cell_nonempty[idx[:, 2], idx[:, 1], idx[:, 0]].any(), (k, j, i)
+        checked += len(ts)
+    assert checked > 50000
+    # not vacuous: some of the non-empty cells see the sun within a few cells, and on average a ray ends well before the box does
+    assert (table[cell_nonempty] * step < 4 * cell).mean() > 0.04
+    assert (table[cell_nonempty] * step).mean() < 1.0
+
+
+def test_shadow_rays_draw_from_their_own_substream(vp):
+    """Counter-based streams: what a path draws after a light estimate does not depend on the shadow ray.  With the sun's power
+    at zero the image is the environment seen by the escaping paths, so two sun directions (shadow rays of different lengths,
+    neither in the camera's view) give the same image bit for bit -- and different ones with the reference's sequential
+    sampler.h stream, where a shadow ray's draws move everything behind it."""
+    import scenes
+    grid = vp.julia_volume(32)
+    W, H = 64, 48
+    out = {}
+    for rng_mode in (vp.RNG_PHILOX7, vp.RNG_PHILOX, vp.RNG_SAMPLERH):
+        for est in (vp.EST_GLOBAL, vp.EST_DECOMP):
+            imgs = []
+            for sun in ((-0.0, 0.951057, -0.309017), (0.0, 0.6, 0.8)):
+                vp.init_volume(grid, brick=1, linear=True)
+                vp.init_envmap(scenes.synthetic_env())
+                vp.set_sun(sun, (0.0, 0.0, 0.0))
+                vp.set_camera()
+                vp.set_estimator(est)
+                vp.set_tracking(0)
+                vp.set_shard(0, 1)
+                vp.set_rng(rng_mode, (5, 6))
+                P = vp.make_param(W, H)
+                buf = vp.DeviceBuffer(W, H)
+                vp.render_frames(buf.ptr, 0, 6, P)
+                imgs.append(buf.download())
+                buf.free()
+            out[(rng_mode, est)] = np.array_equal(imgs[0], imgs[1])
+            assert imgs[0][..., 3].max() > 0  # paths do scatter
+    for est in (vp.EST_GLOBAL, vp.EST_DECOMP):
+        assert out[(vp.RNG_PHILOX7, est)] and out[(vp.RNG_PHILOX, est)]
+        assert not out[(vp.RNG_SAMPLERH, est)]
+
+
 def test_null_collision_table_is_the_float32_recurrence(vp):
     """The light kernel of the global-majorant estimator looks a path's throughput up by its number of null collisions in empty
     space (vp_kernels.hip thr_table_k).  The table restated here in numpy binary32, operation by operation, from the reference's
