@@ -82,7 +82,8 @@ struct State
     unsigned long long* d_counters = nullptr;
     bool        count       = false;
     unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS, setup_lanes = VP_SETUP_LANES, light_wait_iters = 0;  // 0 = by estimator
-    unsigned    blocks_per_cu = 6;  // resident 256-thread workgroups per CU (the register budget of each kernel decides how many really are)
+    unsigned    blocks_per_cu = 5;  // resident 256-thread workgroups per CU of a kernel that runs alone (the general kernels hold 94-96 vector
+                                    // registers: five waves per SIMD)
     bool        use_lds_bounds = true;
     // where the restart crawl in front of the volume ends, per pixel (crawl_table_k); rebuilt when what it depends on changes
     bool        use_crawl_table = true;
@@ -117,6 +118,14 @@ struct State
     unsigned short* d_sunclip = nullptr;
     float       sunclip_ds  = 0.0f;
     std::vector<unsigned char> sunclip_key;
+    // the samples of the light class are per-pixel constants when a null collision in empty space leaves a throughput of 1
+    // exactly 1 (light_identity_k): decided per (medium, estimator, volume), then miss_fill_k writes them
+    bool        use_light_const = true;
+    unsigned*   d_light_flag = nullptr;   // [0] the flag, [1..8] the bytes that occur as maxima in the bound table
+    bool        bound_mask_valid = false;
+    float       light_key[7] = {};
+    unsigned long long light_epoch = ~0ull;
+    bool        light_const = false;
     float*      d_thr       = nullptr;    // throughput after n null collisions in empty space (light kernel, global majorant)
     float       thr_key[5]  = {};
     bool        thr_valid   = false;
@@ -227,6 +236,7 @@ int ensure_device()
     if (knob("VP_NO_CRAWL_TABLE", 0, 1, v)) G.use_crawl_table = v == 0;
     if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;
     if (knob("VP_NO_SUN_CLIP", 0, 1, v)) G.use_sun_clip = v == 0;
+    if (knob("VP_NO_LIGHT_CONST", 0, 1, v)) G.use_light_const = v == 0;
     if (knob("VP_NO_LIGHT", 0, 1, v)) G.use_light = v == 0;
     if (knob("VP_NO_LIGHT_OVERLAP", 0, 1, v)) G.light_overlap = v == 0;
     if (knob("VP_NO_LIGHT_LOCAL", 0, 1, v)) G.use_light_local = v == 0;
@@ -355,6 +365,7 @@ int do_init_volume_(const void* h_volume, vp_extent ext, bool quantized, const v
         HIPCHK(hipGetLastError());
     }
     else { (void)hipGetLastError(); G.d_danger = nullptr; }  // no memory for it: the estimator fetches every cell, same bits
+    G.bound_mask_valid = false;
     HIPCHK(hipStreamSynchronize(G.stream));  // caller may free h_volume on return (host.cpp:1343); scratch freed by the guard
     S.linear      = G.linear ? 1 : 0;
     G.have_volume = true;
@@ -605,6 +616,43 @@ int ensure_sun_clip(const unsigned short** out, float* ds)
     return VP_OK;
 }
 
+// Are the samples of the light class independent of the draws for this medium (vp_kernels.hip light_identity_k)?  Global-majorant
+// and decomposition estimators with spectral tracking; the bounded estimator's heat channel counts segments, scalar tracking has no
+// light class, float bound tables are not enumerable.
+int ensure_light_const(const Param* p, bool* out)
+{
+    *out = false;
+    if (!G.use_light_const || G.count || G.trk != VP_TRACK_SPECTRAL || G.est == VP_EST_BOUNDED) return VP_OK;
+    const bool local = G.est != VP_EST_GLOBAL;
+    if (local && !G.quant) return VP_OK;
+    const float key[7] = {p->sigma_t.x, p->sigma_t.y, p->sigma_t.z, p->density, p->g, (float)G.est, (float)G.brick};
+    if (G.light_epoch != G.epoch || memcmp(key, G.light_key, sizeof key) != 0)
+    {
+        if (!G.d_light_flag) HIPCHK(hipMalloc((void**)&G.d_light_flag, 9 * sizeof(unsigned)));
+        if (local && !G.bound_mask_valid)
+        {
+            HIPCHK(hipMemsetAsync(G.d_light_flag + 1, 0, 8 * sizeof(unsigned), G.stream));
+            launch_bound_bytes((const unsigned char*)G.d_bounds, (size_t)G.S.bnx * G.S.bny * G.S.bnz, G.d_light_flag + 1, G.stream);
+            HIPCHK(hipGetLastError());
+            G.bound_mask_valid = true;
+        }
+        const unsigned one = 1u;
+        unsigned flag = 0u;
+        HIPCHK(hipMemcpyAsync(G.d_light_flag, &one, sizeof one, hipMemcpyHostToDevice, G.stream));
+        ParamDev P;
+        memcpy(&P, p, sizeof(Param));
+        launch_light_identity(P, local, G.d_light_flag + 1, G.d_light_flag, G.stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&flag, G.d_light_flag, sizeof flag, hipMemcpyDeviceToHost, G.stream));
+        HIPCHK(hipStreamSynchronize(G.stream));
+        G.light_const = flag == 1u;
+        memcpy(G.light_key, key, sizeof key);
+        G.light_epoch = G.epoch;
+    }
+    *out = G.light_const;
+    return VP_OK;
+}
+
 // The light kernel of the global-majorant estimator looks the throughput of a path up by its number of null collisions
 // (vp_kernels.hip thr_table_k); the sequence depends on sigma_t, density and g only.
 int ensure_thr_table(const Param* p, const float** out)
@@ -722,7 +770,13 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     if (rc) return rc;
     rc = ensure_sun_clip(&L.sun_clip, &L.clip_ds);
     if (rc) return rc;
-    if (G.est == VP_EST_GLOBAL && G.n_light)
+    bool light_const = false;
+    if (G.n_light)
+    {
+        rc = ensure_light_const(p, &light_const);
+        if (rc) return rc;
+    }
+    if (G.est == VP_EST_GLOBAL && G.n_light && !light_const)
     {
         rc = ensure_thr_table(p, &L.thr_table);
         if (rc) return rc;
@@ -788,21 +842,30 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             const unsigned bsz  = ldsb ? VP_BLOCK_LDS : VP_BLOCK;
             unsigned waves  = (L.total_items + 63) / 64;
             unsigned blocks = (waves + (bsz / 64) - 1) / (bsz / 64);
-            const bool     both = G.n_light && G.n_general;
+            const bool     both = G.n_light && G.n_general && !light_const;
             unsigned       bpc  = G.blocks_per_cu;
-            // what fits a SIMD's 512 vector registers side by side: global majorant 4 x 80 (achromatic; 88 otherwise) + 3 (2) x 64,
+            // what fits a SIMD's 512 vector registers side by side: global majorant 4 x 96 + 2 x 64,
             // local majorant 5 x 96 + ... the light kernel's blocks take what is left as general blocks retire
-            const bool ach = p->sigma_t.x == p->sigma_t.y && p->sigma_t.y == p->sigma_t.z && p->albedo.x == p->albedo.y && p->albedo.y == p->albedo.z;
             // (local majorant, five 96-register general waves per SIMD: the light kernel's workgroups find room as general ones retire,
             // i.e. mostly at the end -- then as many of them as fit)
-            if (both && cls) bpc = G.light_blocks_per_cu ? G.light_blocks_per_cu : (G.est == VP_EST_GLOBAL ? (ach ? 3u : 2u) : 6u);
+            if (both && cls) bpc = G.light_blocks_per_cu ? G.light_blocks_per_cu : (G.est == VP_EST_GLOBAL ? 2u : 6u);
+            if (!both && cls) bpc = 8u;   // the light kernel alone: 64 registers
             if (both && !cls) bpc = G.general_blocks_per_cu ? G.general_blocks_per_cu : (G.est == VP_EST_GLOBAL ? 4u : 5u);
             unsigned cap    = (unsigned)G.num_cu * (ldsb ? 2u : bpc);
             if (blocks > cap) blocks = cap;
             // the light kernel's paths are long and end rarely: its waves leave the tracking loop for the (refill / environment /
             // write) pass less often than the general kernel's do for their collisions
             L.wait_iters = cls ? (G.light_wait_iters ? G.light_wait_iters : (G.est == VP_EST_GLOBAL ? 128u : 64u)) : G.wait_iters;
-            if (cls)
+            if (cls && light_const)
+            {
+                // the samples of the light class do not depend on the draws in this medium: one constant per pixel, written for
+                // every frame (the environment along the camera ray, as for the box-missing pixels)
+                ClassTimer ct(1, T.stream);
+                launch_miss_fill(S, L, false, T.stream);
+                le = hipGetLastError();
+                ct.stop();
+            }
+            else if (cls)
             {
                 // the light kernel: beside the general one on the target's auxiliary stream when both classes have work
                 hipStream_t ls = T.stream;
@@ -1137,6 +1200,7 @@ int vp_ctx_destroy(vp_ctx* ctx)
         if (D.d_crawl) (void)hipFree(D.d_crawl);
         if (D.d_thr) (void)hipFree(D.d_thr);
         if (D.d_sunclip) (void)hipFree(D.d_sunclip);
+        if (D.d_light_flag) (void)hipFree(D.d_light_flag);
         if (D.d_tiles) (void)hipFree(D.d_tiles);
         if (D.d_tile_rows) (void)hipFree(D.d_tile_rows);
         if (D.d_tile_scratch) (void)hipFree(D.d_tile_scratch);

@@ -36,6 +36,10 @@
 #ifndef VP_LIGHT_MIN_WAVES
 #define VP_LIGHT_MIN_WAVES 8   // the light kernels fit 64 vector registers: two of their waves beside four of a 96-register kernel
 #endif
+#ifndef VP_GLOBAL_MIN_WAVES
+#define VP_GLOBAL_MIN_WAVES 5  // achromatic global-majorant kernel: waves per SIMD its register budget is held to (six cost three
+                               // spilled registers since the collision block also samples the phase function: 1190 vs 1341 Msamples/s on C2)
+#endif
 #ifndef VP_LIGHT_STEPS_PER_PASS
 #define VP_LIGHT_STEPS_PER_PASS 16
 #endif
@@ -91,6 +95,10 @@ void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng
 void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimator, hipStream_t st);
 // throughput of an unscattered global-majorant path after n null collisions with density +0, n = 0..count-1 (thr_table_k)
 void launch_thr_table(const ParamDev& P, float* table, unsigned count, hipStream_t st);
+// mask[8]: the bytes that occur as a maximum in a uchar bound table; flag[0] (preset to 1) is cleared unless a null collision in
+// empty space leaves a throughput of 1 unchanged for every sigma_t' a light path can meet (light_identity_k)
+void launch_bound_bytes(const unsigned char* bounds, size_t nbricks, unsigned* mask, hipStream_t st);
+void launch_light_identity(const ParamDev& P, bool local, const unsigned* mask, unsigned* flag, hipStream_t st);
 // the rank's pixel lists, class by class, on the GPU (pixlist_*_k): d_row_start[tiles_y + 1] = first owned tile of each tile row,
 // d_block_counts[3 * pixel_list_blocks(ntiles)] scratch, d_totals[3] = pixels per class (general, light, box-missing)
 inline unsigned pixel_list_blocks(unsigned ntiles) { return (unsigned)(((size_t)ntiles * 64 + 1023) / 1024); }

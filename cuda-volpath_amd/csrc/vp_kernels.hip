@@ -75,6 +75,51 @@ __global__ void thr_table_k(ParamDev P, float* table, unsigned count)
     }
 }
 
+// ---- when the samples of the light class do not depend on the draws.
+// A light path's throughput starts at (1,1,1) and changes only through null collisions in empty space, each a multiplication by
+// sigma_t' * ((1/sigma_t' * Pn) / Pn) with Pn = 3 |sigma_t' t|.  That factor is exactly 1 at t = 1 for most sigma_t' (800, the
+// default, among them) -- and then the throughput stays exactly 1 whatever the number of collisions, i.e. whatever is drawn: the
+// sample is the environment seen along the camera ray, a per-pixel constant like the samples of a ray that misses the box
+// (quirk Q3), and miss_fill_k writes it.  This kernel decides that with the device's own arithmetic: global majorant: the one
+// sigma_t' of an unscattered path (thr_table_k); decomposition estimator: sigma_t' = max_sig * density * max(0.0001, b / 255) for
+// every byte b that occurs as a maximum in the bound table (bound_bytes_k's mask).  flag[0] = 1 if the factor is 1 for all of them.
+__global__ void bound_bytes_k(const unsigned short* bounds, size_t n, unsigned* mask)
+{
+    __shared__ unsigned m[8];
+    if (threadIdx.x < 8) m[threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    {
+        const unsigned b = bounds[i] & 0xffu;   // the maximum (PairU8)
+        if (!(m[b >> 5] >> (b & 31u) & 1u)) atomicOr(&m[b >> 5], 1u << (b & 31u));
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && m[threadIdx.x]) atomicOr(&mask[threadIdx.x], m[threadIdx.x]);
+}
+__global__ void light_identity_k(ParamDev P, int local, const unsigned* mask, unsigned* flag)
+{
+    const unsigned b = threadIdx.x;   // 256 threads
+    if (local && !(mask[b >> 5] >> (b & 31u) & 1u)) return;
+    if (!local && b) return;
+    const float max_sig = max3(f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]});
+    const float s       = hyperion_s(0 - 5);
+    float sigma_t_prime;
+    if (local)
+    {
+        const float reduction   = (1.0f - s) + s * (1.0f - P.g);           // segment_medium(), no scatter behind the path
+        const float cur_density = reduction * P.density;
+        const float d_max       = fmaxf(0.0001f, (float)b * VP_U8_SCALE);   // segment_setup()
+        sigma_t_prime           = max_sig * cur_density * d_max;
+    }
+    else
+    {
+        const float cur_density = (1.0f - s) * P.density + s * P.density * (1.0f - P.g);   // thr_table_k
+        sigma_t_prime           = max_sig * cur_density;
+    }
+    const float inv_sigma_t = 1.0f / sigma_t_prime;
+    if (!(null_collision_in_empty_space(1.0f, sigma_t_prime, inv_sigma_t) == 1.0f)) atomicAnd(flag, 0u);
+}
+
 // LDSB: the (max,min) brick table of the decomposition estimator is staged through LDS (BASELINE config 3:
 // 256^3 / 8^3 bricks = 32768 byte pairs = 64 KiB).  Those workgroups are 512 threads so that two of them
 // (2 x 64 KiB of the CU's 160 KiB) keep 16 waves per CU resident.
@@ -94,7 +139,7 @@ template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool 
 // asking for five costs no spill and is +10 % on the reference-table decomposition workload.  The global-majorant
 // kernel fits six waves (80 VGPRs, no spill): +3 % now that the queue order keeps the L2 hit rate above 90 %.
 __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK,
-                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : VP_LIGHT_MIN_WAVES) : MIS || LDSB ? 1 : (EST == EST_GLOBAL && ACH && TRK == 0 ? 6 : 5)))
+                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : VP_LIGHT_MIN_WAVES) : MIS || LDSB ? 1 : (EST == EST_GLOBAL && ACH && TRK == 0 ? VP_GLOBAL_MIN_WAVES : 5)))
 void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
@@ -108,6 +153,12 @@ void render_k(SceneDev S, LaunchDev L)
         __syncthreads();
     }
     constexpr bool LOCAL = EST != EST_GLOBAL;  // the two local-majorant estimators share the segment logic
+    // Counter-based streams, passive environment: ONE event visit per collision.  The shadow ray draws from a sub-stream of its own,
+    // so the two phase-function variates -- the path's next draws -- are the same whether they are taken before or after it: the
+    // new direction is sampled in the collision block (and, global majorant, the box is intersected for it), the shadow ray is
+    // tracked, and where it ends the tracking step itself adds the light and goes on with the new segment.  The sequential
+    // sampler.h stream (and the MIS build) keep the reference's order: collision, shadow ray, light, phase function.
+    constexpr bool EARLY = RNG::kShadowSubstream && !MIS && !LIGHT;
     const ParamDev& P = L.P;
     const f3    sig_t     = f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]};
     const f3    sig_s     = sig_t * f3{P.albedo[0], P.albedo[1], P.albedo[2]};
@@ -251,6 +302,12 @@ void render_k(SceneDev S, LaunchDev L)
             if ((EST == EST_BOUNDED ? seg : nsc) >= 800) st = EV_WRITE;
             segment_medium();
         };
+        // EARLY: the light estimate is known without a shadow ray (optical-depth table, or the ray misses the box)
+        auto finish_light = [&]() __attribute__((always_inline)) {
+            rad = rad + sun_power * (((ACH ? f3{thr.x, thr.x, thr.x} : thr) * ph) * nee_a);
+            rd  = pd;
+            next_segment();
+        };
         // ---- collision: direct lighting set-up (kernel.cu:2161-2217 / :1458-1491)
         tally(B_SCATTER, st == EV_SCATTER);
         if (!LIGHT && st == EV_SCATTER)
@@ -280,6 +337,15 @@ void render_k(SceneDev S, LaunchDev L)
             }
             ph = hg_eval(phase_g, dot(rd, sun_dir));
             pd = rd;
+            if (EARLY)
+            {
+                // the direction the path takes up when the light estimate is in (kernel.cu:2301-2303)
+                Frame fr(rd);
+                float r0 = rng.next_a();
+                float r1 = rng.next_b();
+                pd       = normalize(fr.to_world(hg_sample_local(phase_g, r0, r1)));
+                if (LOCAL) inv_rd = f3{1.0f / pd.x, 1.0f / pd.y, 1.0f / pd.z};
+            }
             if (MIS)
             {
                 sh_inv_sigma = 1.0f / stp2;
@@ -310,16 +376,30 @@ void render_k(SceneDev S, LaunchDev L)
                     nee_a  = f3{expf_(tau.x), expf_(tau.y), expf_(tau.z)};
                 }
                 st     = EV_NEE;
+                if (EARLY) finish_light();
             }
             else
+            {
                 start_shadow(sun_dir * 1e10f, 1.0f / stp2, dp2, 0u);
+                if (EARLY && st == EV_NEE) finish_light();   // the ray misses the box
+                if (EARLY && EST == EST_GLOBAL && st == ST_SHADOW)
+                {
+                    // the set-up of the next segment (kernel.cu:1332-1345) for the new direction, while the lane is here anyway:
+                    // where it enters (kept in t_empty, which is 0 for a scattered path and not read by shadow steps) and leaves
+                    // the box (t_far; negative = it does not: the path ends with the environment)
+                    float tn2, tf2;
+                    bool  hit2 = intersect_box(ro, pd, S, tn2, tf2);
+                    t_empty    = tn2 < 0.0f ? 0.0f : tn2;
+                    t_far      = hit2 ? tf2 : -1.0f;
+                }
+            }
         }
 #pragma unroll
         for (int pass = 0; pass < (MIS ? 2 : 1); pass++)
         {
             // ---- a light estimate is complete (kernel.cu:2188-2189,:2209-2210 and :2254,:2290)
             tally(B_NEE, st == EV_NEE);
-            if (!LIGHT && st == EV_NEE)
+            if (!LIGHT && !EARLY && st == EV_NEE)
             {
                 if (MIS)
                 {
@@ -383,7 +463,7 @@ void render_k(SceneDev S, LaunchDev L)
         }
         // ---- phase-function sampling (kernel.cu:2301-2303)
         tally(B_HG, st == EV_HG);
-        if (!LIGHT && st == EV_HG)
+        if (!LIGHT && !EARLY && st == EV_HG)
         {
             Frame fr(pd);
             float r0 = rng.next_a();
@@ -620,6 +700,53 @@ void render_k(SceneDev S, LaunchDev L)
                 }
             }
         };
+        // EARLY: a shadow ray has ended (nee_a known): add the light and go on with the segment prepared in the collision block
+        auto light_done = [&]() __attribute__((always_inline)) {
+            const char* ka_ = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka_));   // the sun's power is read here, not held in scalar registers across the loop
+            const SceneDev& S2 = *reinterpret_cast<const SceneDev*>(ka_);
+            const f3 sunp = f3{S2.sun_power[0], S2.sun_power[1], S2.sun_power[2]};
+            rad = rad + sunp * (((ACH ? f3{thr.x, thr.x, thr.x} : thr) * ph) * nee_a);
+            rd  = pd;
+            if (EST == EST_GLOBAL)
+            {
+                nsc++;
+                if (nsc >= 800) st = EV_WRITE;
+                else if (t_far < 0.0f) { st = EV_BG; t_empty = 0.0f; }
+                else
+                {
+                    // __d_render's segment set-up kernel.cu:1355-1370 for the depth index just reached
+                    t_end         = t_far;
+                    dist          = t_empty;
+                    t_empty       = 0.0f;
+                    float s       = hyperion_s(nsc - 5);
+                    phase_g       = (1.0f - s) * P.g;
+                    if (TRK)
+                    {
+                        sigma_t_prime = (1.0f - s) * sig_base + s * sig_base * (1.0f - P.g);
+                        cur_density   = sigma_t_prime;
+                    }
+                    else
+                    {
+                        cur_density   = (1.0f - s) * density + s * density * (1.0f - P.g);
+                        sigma_t_prime = max_sig * cur_density;
+                    }
+                    inv_sigma     = 1.0f / sigma_t_prime;
+                    inv_sigma_t   = inv_sigma;
+                    st            = ST_TRACK;
+                }
+            }
+            else
+            {
+                st = ST_SETUP;
+                if (EST == EST_BOUNDED) seg++;
+                if ((EST == EST_BOUNDED ? seg : nsc) >= 800) st = EV_WRITE;
+                float s         = hyperion_s(nsc - 5);
+                phase_g         = (1.0f - s) * P.g;
+                float reduction = (1.0f - s) + s * (1.0f - P.g);
+                cur_density     = TRK ? reduction * sig_base : reduction * density;
+            }
+        };
         auto tracking_step = [&]() __attribute__((always_inline)) {
             tally(B_HALF, st == ST_TRACK || st == ST_SHADOW);
             if (LIGHT && !LOCAL)
@@ -661,6 +788,7 @@ void render_k(SceneDev S, LaunchDev L)
                         nee_a = f3{(float)(1 - (terms & 1)), (float)(1 - ((terms >> 1) & 1)), (float)(1 - ((terms >> 2) & 1))};
                         st    = EV_NEE;
                         rng.leave_shadow();
+                        if (EARLY) light_done();
                     }
                     else if (LOCAL)
                     {
@@ -716,7 +844,7 @@ void render_k(SceneDev S, LaunchDev L)
                         // scalar delta tracking: kernel.cu:2137-2142 / :745-748 (Tr stops AT its collision, no further draw)
                         if (e < den * inv_sigma)
                         {
-                            if (shadow) { nee_a = f3{0.0f, 0.0f, 0.0f}; st = EV_NEE; rng.leave_shadow(); }
+                            if (shadow) { nee_a = f3{0.0f, 0.0f, 0.0f}; st = EV_NEE; rng.leave_shadow(); if (EARLY) light_done(); }
                             else { ro = p; st = EV_SCATTER; }
                         }
                     }
@@ -1623,6 +1751,15 @@ void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng
     else VP_LE(RngSamplerH);
 #endif
 #undef VP_LE
+}
+void launch_bound_bytes(const unsigned char* bounds, size_t nbricks, unsigned* mask, hipStream_t st)
+{
+    unsigned blocks = (unsigned)std::fmin((double)((nbricks + 255) / 256), 1024.0);
+    hipLaunchKernelGGL(bound_bytes_k, dim3(blocks ? blocks : 1), dim3(256), 0, st, reinterpret_cast<const unsigned short*>(bounds), nbricks, mask);
+}
+void launch_light_identity(const ParamDev& P, bool local, const unsigned* mask, unsigned* flag, hipStream_t st)
+{
+    hipLaunchKernelGGL(light_identity_k, dim3(1), dim3(256), 0, st, P, local ? 1 : 0, mask, flag);
 }
 void launch_thr_table(const ParamDev& P, float* table, unsigned count, hipStream_t st)
 {
