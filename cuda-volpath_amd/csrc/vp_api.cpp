@@ -85,6 +85,7 @@ struct State
     unsigned    blocks_per_cu = 5;  // resident 256-thread workgroups per CU of a kernel that runs alone (the general kernels hold 94-96 vector
                                     // registers: five waves per SIMD)
     bool        use_lds_bounds = true;
+    int         cell_bricks = 0;          // packed cells in 4x4x4 bricks (VP_CELL_BRICKS=1; an A/B knob, see do_init_volume_)
     // where the restart crawl in front of the volume ends, per pixel (crawl_table_k); rebuilt when what it depends on changes
     bool        use_crawl_table = true;
     bool        use_empty_table = true;   // global-majorant estimator: certified-empty distances of the camera rays
@@ -233,6 +234,7 @@ int ensure_device()
     if (knob("VP_STAGE_MB", 1, 256 << 10, v)) G.max_stage_bytes = (size_t)v << 20;
     if (knob("VP_BLOCKS_PER_CU", 1, 8, v)) G.blocks_per_cu = (unsigned)v;
     if (knob("VP_NO_LDS_BOUNDS", 0, 1, v)) G.use_lds_bounds = v == 0;
+    if (knob("VP_CELL_BRICKS", 0, 1, v)) G.cell_bricks = (int)v;
     if (knob("VP_NO_CRAWL_TABLE", 0, 1, v)) G.use_crawl_table = v == 0;
     if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;
     if (knob("VP_NO_SUN_CLIP", 0, 1, v)) G.use_sun_clip = v == 0;
@@ -329,9 +331,18 @@ int do_init_volume_(const void* h_volume, vp_extent ext, bool quantized, const v
     const size_t vbytes = n * (quantized ? 1 : 4);
     HIPCHK(hipMalloc(&d_raw, vbytes));
     HIPCHK(hipMemcpyAsync(d_raw, h_volume, vbytes, hipMemcpyHostToDevice, G.stream));
-    HIPCHK(hipMalloc(&G.d_cells, n * (quantized ? 8 : 32)));
-    if (quantized) launch_pack_u8((const unsigned char*)d_raw, (uint2*)G.d_cells, nx, ny, nz, G.stream);
-    else launch_pack_f32((const float*)d_raw, (float*)G.d_cells, nx, ny, nz, G.stream);
+    // cell layout: x fastest (default), or 4x4x4 bricks of cells (VP_CELL_BRICKS=1).  Measured on every workload incl. the two
+    // 512^3 ones whose cells (1.07 GB) are outside every cache (profiles/r03_cell_layout_ab.txt): fabric reads -3...-12 %, L2 hit
+    // rate +1...+3 points, Msamples/s within 1 % (c3ref -2 %) -- the rays of a wave are too many and too incoherent for either order
+    // to keep their lines in a 4 MiB L2.  The x-fastest order stays; the knob is kept for the A/B.
+    const size_t ncells_bricks = (((size_t)nx + 3) / 4) * (((size_t)ny + 3) / 4) * (((size_t)nz + 3) / 4) * 64;
+    const bool   bricks = G.cell_bricks > 0;
+    const size_t ncells = bricks ? ncells_bricks : n;
+    S.cell_bricks = bricks ? 1 : 0;
+    HIPCHK(hipMalloc(&G.d_cells, ncells * (quantized ? 8 : 32)));
+    if (bricks && ncells != n) HIPCHK(hipMemsetAsync(G.d_cells, 0, ncells * (quantized ? 8 : 32), G.stream));   // the padding of partial bricks
+    if (quantized) launch_pack_u8((const unsigned char*)d_raw, (uint2*)G.d_cells, nx, ny, nz, bricks, G.stream);
+    else launch_pack_f32((const float*)d_raw, (float*)G.d_cells, nx, ny, nz, bricks, G.stream);
     HIPCHK(hipGetLastError());
     // bound table: three separable max/min passes + brick reduction on the GPU (replaces host.cpp:1088-1267)
     G.brick  = G.brick_next;
@@ -770,6 +781,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     if (rc) return rc;
     rc = ensure_sun_clip(&L.sun_clip, &L.clip_ds);
     if (rc) return rc;
+    L.count_clips = getenv("VP_DEBUG_COUNT_CLIPS") ? 1u : 0u;
     bool light_const = false;
     if (G.n_light)
     {
@@ -825,6 +837,19 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         hipEvent_t e0 = get_event(), e1 = get_event();
         bool timed = e0 && e1 && hipEventRecord(e0, T.stream) == hipSuccess;
         hipError_t le = hipSuccess;
+        // the fork point of the light kernel's auxiliary stream: BEFORE the general kernel is queued (the two run side by side),
+        // after the queue heads are zeroed; an event of its own, created on first use
+        bool fork_recorded = false;
+        if (G.n_light && G.n_general && !light_const && G.light_overlap)
+        {
+            const int ti = T.index;
+            if (!G.aux_ev[ti][0] && hipEventCreateWithFlags(&G.aux_ev[ti][0], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G.aux_ev[ti][0] = nullptr; }
+            if (G.aux_ev[ti][0])
+            {
+                fork_recorded = hipEventRecord(G.aux_ev[ti][0], T.stream) == hipSuccess;
+                if (!fork_recorded) (void)hipGetLastError();
+            }
+        }
         // one launch per pixel class: the general pixels, then the light ones (their own kernel, their own sample queues)
         for (int cls = 0; cls < 2 && le == hipSuccess; cls++)
         {
@@ -875,7 +900,14 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                     if (!G.aux_stream[ti] && hipStreamCreateWithFlags(&G.aux_stream[ti], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); G.aux_stream[ti] = nullptr; }
                     for (int q = 0; q < 2; q++)
                         if (!G.aux_ev[ti][q] && hipEventCreateWithFlags(&G.aux_ev[ti][q], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G.aux_ev[ti][q] = nullptr; }
-                    if (G.aux_stream[ti] && G.aux_ev[ti][0] && G.aux_ev[ti][1] && e0 && hipStreamWaitEvent(G.aux_stream[ti], e0, 0) == hipSuccess) ls = G.aux_stream[ti];
+                    // the auxiliary stream starts at the fork point recorded above (queue heads zeroed, the previous launch's reduce,
+                    // uploads: everything queued on the target stream before the general kernel); it is used only if both the record
+                    // and the wait succeeded (waiting on an unrecorded event returns at once)
+                    if (G.aux_stream[ti] && G.aux_ev[ti][0] && G.aux_ev[ti][1] && fork_recorded)
+                    {
+                        if (hipStreamWaitEvent(G.aux_stream[ti], G.aux_ev[ti][0], 0) == hipSuccess) ls = G.aux_stream[ti];
+                        else (void)hipGetLastError();
+                    }
                 }
                 ClassTimer ct(1, ls);
                 launch_render_light(S, L, G.est, G.rng, G.quant, G.count, (int)blocks, ls);

@@ -22,7 +22,7 @@
 // the inner tracking loop of a wave runs until this many lanes are parked on an event, or until
 // a parked lane has waited this many steps
 #ifndef VP_WAIT_LANES
-#define VP_WAIT_LANES 16
+#define VP_WAIT_LANES 24
 #endif
 #ifndef VP_WAIT_ITERS
 #define VP_WAIT_ITERS 16
@@ -84,6 +84,8 @@ struct LaunchDev
     // anywhere in the cell toward the sun meets empty cells only (sun_clip_k); a sun shadow ray ends there.  Null = walk to the end.
     const unsigned short* sun_clip;
     float    clip_ds;
+    unsigned count_clips;   // counting build: 0 = walk every shadow ray to its end (density_lookups = the estimator's count, as the oracle's),
+                            // 1 = end them where the timed build does (VP_DEBUG_COUNT_CLIPS: block tallies of what the timed kernels execute)
     const float* thr_table; // light kernel of the global-majorant estimator: thr_table[n] = throughput after n null collisions in empty
     unsigned thr_n;         // space (thr_table_k: a function of n alone there), n < thr_n; beyond the table the recurrence is run
 };
@@ -113,8 +115,9 @@ float sun_clip_step(const SceneDev& S);  // the table's distance unit: a quarter
 void launch_sun_clip(const SceneDev& S, const unsigned char* danger, float ds, unsigned short* out, hipStream_t st);
 void launch_empty_table(const SceneDev& S, unsigned width, unsigned height, const unsigned char* danger, float4* table, hipStream_t st);
 void launch_reduce(const LaunchDev& L, hipStream_t st);
-void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, hipStream_t st);
-void launch_pack_f32(const float* vol, float* cells, int nx, int ny, int nz, hipStream_t st);
+// bricks: cells in 4x4x4 bricks (vp_device.h cell_index); the buffer then holds ceil(n/4)^3 * 64 cells
+void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, bool bricks, hipStream_t st);
+void launch_pack_f32(const float* vol, float* cells, int nx, int ny, int nz, bool bricks, hipStream_t st);
 void launch_opacity(const SceneDev& S, bool quant, const float dir[3], float* out, hipStream_t st);
 void launch_build_bounds(const void* d_vol, bool quant, void* d_out, void* d_tmp_a, void* d_tmp_b, int nx, int ny, int nz, int radius, int brick,
                          hipStream_t st);

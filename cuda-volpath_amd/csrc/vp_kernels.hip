@@ -277,7 +277,7 @@ void render_k(SceneDev S, LaunchDev L)
                     if (n != 0xffffu)
                     {
                         const float tc = (float)n * L.clip_ds;
-                        if (COUNT) t_clip = tc;
+                        if (COUNT && !L.count_clips) t_clip = tc;
                         else t_end = fminf(t_end, tc);
                     }
                 }
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(256) void danger_k(SceneDev S, unsigned char* out)
             for (int di = -1; di <= 1; di++)
             {
                 int a = min(max(i + di, 0), S.nx - 1), b = min(max(j + dj, 0), S.ny - 1), c = min(max(k + dk, 0), S.nz - 1);
-                size_t o = (size_t)a + (size_t)S.nx * ((size_t)b + (size_t)S.ny * c);
+                size_t o = cell_index(S, a, b, c);
                 if (QUANT) { uint2 v = S.cells_u8[o]; any = any || (v.x | v.y) != 0u; }
                 else
                 {
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(256) void danger_k(SceneDev S, unsigned char* out)
     // bit 0: a non-empty cell in the 3x3x3 neighbourhood; bit 1: this cell itself is non-empty
     bool self;
     {
-        size_t o = idx;
+        size_t o = cell_index(S, i, j, k);
         if (QUANT) { uint2 v = S.cells_u8[o]; self = (v.x | v.y) != 0u; }
         else
         {
@@ -1359,7 +1359,13 @@ __global__ __launch_bounds__(256) void miss_fill_k(SceneDev S, LaunchDev L, int 
 }
 
 // expand a dense volume into per-voxel 2x2x2 neighbourhood cells (clamped at the border)
-__global__ void pack_cells_u8_k(const unsigned char* vol, uint2* cells, int nx, int ny, int nz)
+__device__ __forceinline__ size_t pack_index(int nx, int ny, int i, int j, int k, int bricks)
+{
+    if (!bricks) return (size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k);
+    const size_t nbx = ((size_t)nx + 3) >> 2, nby = ((size_t)ny + 3) >> 2;
+    return ((((size_t)i >> 2) + nbx * (((size_t)j >> 2) + nby * ((size_t)k >> 2))) << 6) | (size_t)(((k & 3) << 4) | ((j & 3) << 2) | (i & 3));
+}
+__global__ void pack_cells_u8_k(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, int bricks)
 {
     size_t n   = (size_t)nx * ny * nz;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1370,9 +1376,9 @@ __global__ void pack_cells_u8_k(const unsigned char* vol, uint2* cells, int nx, 
     uint2 c;
     c.x = at(i, j, k) | (at(i1, j, k) << 8) | (at(i, j1, k) << 16) | (at(i1, j1, k) << 24);
     c.y = at(i, j, k1) | (at(i1, j, k1) << 8) | (at(i, j1, k1) << 16) | (at(i1, j1, k1) << 24);
-    cells[idx] = c;
+    cells[pack_index(nx, ny, i, j, k, bricks)] = c;
 }
-__global__ void pack_cells_f32_k(const float* vol, float* cells, int nx, int ny, int nz)
+__global__ void pack_cells_f32_k(const float* vol, float* cells, int nx, int ny, int nz, int bricks)
 {
     size_t n   = (size_t)nx * ny * nz;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1380,7 +1386,7 @@ __global__ void pack_cells_f32_k(const float* vol, float* cells, int nx, int ny,
     int i = (int)(idx % nx), j = (int)((idx / nx) % ny), k = (int)(idx / ((size_t)nx * ny));
     int i1 = i + 1 < nx ? i + 1 : nx - 1, j1 = j + 1 < ny ? j + 1 : ny - 1, k1 = k + 1 < nz ? k + 1 : nz - 1;
     auto at = [&](int a, int b, int c) -> float { return vol[(size_t)a + (size_t)nx * ((size_t)b + (size_t)ny * c)]; };
-    float4* q = reinterpret_cast<float4*>(cells) + idx * 2;
+    float4* q = reinterpret_cast<float4*>(cells) + pack_index(nx, ny, i, j, k, bricks) * 2;
     q[0] = make_float4(at(i, j, k), at(i1, j, k), at(i, j1, k), at(i1, j1, k));
     q[1] = make_float4(at(i, j, k1), at(i1, j, k1), at(i, j1, k1), at(i1, j1, k1));
 }
@@ -1944,15 +1950,15 @@ void launch_reduce(const LaunchDev& L, hipStream_t st)
     unsigned per_frame = L.nslots;
     hipLaunchKernelGGL(reduce_stage_k, dim3((per_frame + 255) / 256), dim3(256), 0, st, L);
 }
-void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, hipStream_t st)
+void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, bool bricks, hipStream_t st)
 {
     size_t n = (size_t)nx * ny * nz;
-    hipLaunchKernelGGL(pack_cells_u8_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vol, cells, nx, ny, nz);
+    hipLaunchKernelGGL(pack_cells_u8_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vol, cells, nx, ny, nz, bricks ? 1 : 0);
 }
-void launch_pack_f32(const float* vol, float* cells, int nx, int ny, int nz, hipStream_t st)
+void launch_pack_f32(const float* vol, float* cells, int nx, int ny, int nz, bool bricks, hipStream_t st)
 {
     size_t n = (size_t)nx * ny * nz;
-    hipLaunchKernelGGL(pack_cells_f32_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vol, cells, nx, ny, nz);
+    hipLaunchKernelGGL(pack_cells_f32_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vol, cells, nx, ny, nz, bricks ? 1 : 0);
 }
 void launch_opacity(const SceneDev& S, bool quant, const float dir[3], float* out, hipStream_t st)
 {

@@ -228,6 +228,7 @@ int main(int argc, char** argv)
         free_cuda_buffers();
         free_envmap();
     }
+    reducer.shutdown();   // communicators first: their collectives ran on the contexts' streams
     if (gpus > 1) { vp_ctx_set_current(nullptr); for (auto c : ctx) vp_ctx_destroy(c); }
     return 0;
 }

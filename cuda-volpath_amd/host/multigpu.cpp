@@ -129,9 +129,14 @@ bool NodeReducer::reduce_to_root(const std::vector<vp_ctx*>& ctx, const std::vec
     return true;
 }
 
-NodeReducer::~NodeReducer()
+void NodeReducer::shutdown()
 {
     for (void* c : comms_) R.CommDestroy((ncclComm_t)c);
+    comms_.clear();
+}
+NodeReducer::~NodeReducer()
+{
+    shutdown();
     if (lib_) dlclose(lib_);
 }
 }  // namespace volpath

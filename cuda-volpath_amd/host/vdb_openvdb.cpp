@@ -1,6 +1,6 @@
 // vdb_openvdb.cpp -- load_vdb(): the first FloatGrid of an OpenVDB file as a dense float array (vdbloader/load_vdb.cpp:72-157).
 //
-// Compiled only where OpenVDB is installed (Makefile probe for <openvdb/openvdb.h>, -DVOLPATH_WITH_OPENVDB).  The image this
+// Compiled only on request (`make VOLPATH_WITH_OPENVDB=1`, -DVOLPATH_WITH_OPENVDB) where OpenVDB is installed.  The image this
 // project is developed in has no OpenVDB: THIS FILE HAS NEVER BEEN COMPILED OR RUN.  It states the conversion the reference
 // performs, against OpenVDB's public API:
 //   * the grid that is converted is the first one in the file that is a FloatGrid (load_vdb.cpp:135-153);
@@ -32,6 +32,11 @@ float* load_vdb(char* filename, int& width, int& height, int& depth, float& min_
 
     const openvdb::CoordBBox box = grid->evalActiveVoxelBoundingBox();
     const openvdb::Coord     lo = box.min(), dim = box.dim();
+    if (box.empty() || dim.x() <= 0 || dim.y() <= 0 || dim.z() <= 0)
+    {
+        fprintf(stderr, "load_vdb('%s'): the float grid has no active voxel\n", filename);
+        return nullptr;
+    }
     width = dim.x(); height = dim.y(); depth = dim.z();
     grid->evalMinMax(min_value, max_value);
     const size_t nx = (size_t)dim.x(), ny = (size_t)dim.y(), total = nx * ny * (size_t)dim.z();

@@ -67,7 +67,17 @@ def host_volume(workload, oracle=None):
         if not host.dump_dense(path, vol):
             raise RuntimeError("dump_dense_volume failed")
         del vol
-        grid = host.load_binary(path, quantized=True)
+        # loadBinaryFile reports what it read on stdout, as the reference's does (host.cpp:940): keep that off the stdout of a
+        # caller that prints ONE JSON line there (bench.py)
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            grid = host.load_binary(path, quantized=True)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         if grid is None:
             raise RuntimeError("loadBinaryFile failed")
     finally:

@@ -6,10 +6,10 @@ TAG=${1:-r01}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --no-cpu-baseline "$@" > $OUT/bench_kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 "$@" > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 "$@" > $OUT/bench_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 "$@" > $OUT/bench_sq.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/tcc -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 "$@" > $OUT/bench_tcc.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --no-cpu-baseline --no-secondary "$@" > $OUT/bench_kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 "$@" > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 "$@" > $OUT/bench_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq -- python3 bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 "$@" > $OUT/bench_sq.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/tcc -- python3 bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 "$@" > $OUT/bench_tcc.log 2>&1
 python3 scripts/profile_digest.py $OUT > $OUT/digest.json
 cat $OUT/digest.json

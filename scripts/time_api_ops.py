@@ -1,5 +1,7 @@
-import sys, time
-sys.path.insert(0,'/root/repo/tests'); sys.path.insert(0,'/root/repo/cuda-volpath_amd')
+"""wall time of the C-ABI entry points on a tiny scene (development tool): python scripts/time_api_ops.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'cuda-volpath_amd'))
 import numpy as np, volpath as vp, scenes, oracle_lib as oracle
 vp.set_device(0)
 grid = oracle.julia(16)

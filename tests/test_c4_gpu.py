@@ -447,3 +447,111 @@ def test_class_times_and_prepare(vp):
     assert launches >= 1 and total >= max(ms.values()) * 0.9
     ms2, _ = vp.render_class_time_ms(reset=True)
     assert all(v == 0 for v in ms2.values())
+
+
+# ------------------------------------------------------------------ c4f: the same shape with a volume that fills the frame
+@pytest.fixture(scope="module")
+def c4f(vp):
+    from volpath import scene as vscene
+    P, info = vscene.setup("c4f", rng_mode=vp.RNG_PHILOX7, last_frame=64)
+    assert (P.width, P.height) == (1280, 720) and info["n"] == 512 and info["chromatic"] and "SYNTHETIC" in info["volume"]
+    return P, info
+
+
+def test_c4f_fills_the_frame_and_has_soft_densities(vp, c4f):
+    """What the frame-filling stand-in is for: every camera ray enters the box, at least 70 % of the pixels are `general` (a cloud
+    leaves few rays that never meet the medium -- the Julia stand-in c4s leaves 88 %), and the bound table sees minima and
+    maxima that differ from 0 / 255 (non-binary densities: quirk Q4's local majorant and the control component are active)."""
+    P, info = c4f
+    vp.set_estimator(vp.EST_DECOMP)
+    vp.set_shard(0, 1)
+    cls = np.bincount(vp.pixel_table(P)[..., 5].astype(int).ravel(), minlength=3) / float(P.width * P.height)
+    assert cls[2] == 0.0 and cls[0] >= 0.70, cls
+    bounds, brick, radius = vp.bound_table()
+    assert brick == 16
+    mx, mn = bounds[..., 0], bounds[..., 1]
+    assert ((mx > 0) & (mx < 255)).mean() > 0.05 and (mn > 0).mean() > 0.01
+    assert 0.03 < info["occupancy"] < 0.5
+
+
+def test_c4f_batched_equals_frame_by_frame_and_shards_add_up(vp, c4f):
+    P, info = c4f
+    W, H = P.width, P.height
+    vp.set_estimator(vp.EST_DECOMP)
+    vp.set_rng(vp.RNG_PHILOX7, (0x9E3779B9, 0x85EBCA6B))
+    vp.set_shard(0, 1)
+    a, b = vp.DeviceBuffer(W, H), vp.DeviceBuffer(W, H)
+    frames = range(10, 13)                                  # across the frame-11 estimator switch (quirk Q5)
+    vp.render_frames(a.ptr, frames[0], len(frames), P)
+    for f in frames:
+        vp.render_kernel(b.ptr, f, P)
+    whole = a.download()
+    assert np.array_equal(whole, b.download())
+    assert np.isfinite(whole).all() and (whole >= 0).all()
+    assert (whole[..., 3] > 0).mean() > 0.6                 # most pixels scatter
+    b.free()
+    from volpath import dist as vd
+    for world in (2, 8):
+        tot = np.zeros_like(whole)
+        for r in range(world):
+            a.reset()
+            vp.set_shard(r, world)
+            vp.render_frames(a.ptr, frames[0], len(frames), P)
+            part = a.download()
+            assert not part[~vd.owned_mask(r, world, W, H)].any()
+            tot += part
+        assert np.array_equal(tot, whole), world
+    vp.set_shard(0, 1)
+    a.free()
+
+
+def test_cloud_workload_is_bit_exact_at_reduced_size(vp, oracle, tmp_path):
+    """The c4f recipe -- synthetic cloud as float, dump_dense_volume, loadBinaryFile + quantiser, chromatic preset #1, the
+    workload's own camera, decomposition tracking over a brick table -- at 48^3 / 96x54 against the oracle, tolerance 0,
+    images and work counters, across the frame-11 switch; Philox2x32-7 (shadow sub-streams, sun table, light class)."""
+    from volpath import host, scene as vscene
+    cfg = vscene.WORKLOADS["c4f"]
+    n, W, H = 48, 96, 54
+    vol = vp.cloud_volume(n, cfg["seed"])
+    path = str(tmp_path / "cloud.bin")
+    assert host.dump_dense(path, vol)
+    grid = host.load_binary(path, quantized=True)
+    cam = vscene.camera_of(cfg)
+    env = scenes.synthetic_env()
+    for est, brick in ((oracle.EST_DECOMP, 4), (oracle.EST_GLOBAL, 1)):
+        osc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, brick=brick, estimator=est,
+                                 rng_mode=oracle.RNG_PHILOX7, seed=(3, 4), inv_view=cam)
+        osc.precompute_opacity()
+        oP, vP = oracle.default_param(W, H, density=60.0), vp.make_param(W, H, density=60.0)
+        oracle.mat(oP, *scenes.PRESET1)
+        vp.mat(vP, *scenes.PRESET1)
+        vp.init_volume(grid, brick=brick, linear=True)
+        vp.init_envmap(env)
+        vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+        vp.set_camera(cam)
+        vp.set_estimator(est)
+        vp.set_tracking(0)
+        vp.set_rng(vp.RNG_PHILOX7, (3, 4))
+        vp.set_shard(0, 1)
+        vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+        frames = range(9, 13)
+        ref, tot = None, None
+        for f in frames:
+            ref, c = osc.render_frame(oP, f, ref)
+            d = c.as_dict()
+            tot = d if tot is None else {k: tot[k] + d[k] for k in d}
+        buf = vp.DeviceBuffer(W, H)
+        vp.enable_counters(True)
+        vp.read_counters(reset=True)
+        vp.render_frames(buf.ptr, frames[0], len(frames), vP)
+        cnt = vp.read_counters(reset=True)
+        vp.enable_counters(False)
+        assert np.array_equal(buf.download(), ref), est
+        for k in ("density_lookups", "bound_lookups", "env_lookups", "scatters", "opacity_lookups"):
+            assert cnt[k] == tot[k], (est, k, cnt[k], tot[k])
+        buf.reset()
+        vp.render_frames(buf.ptr, frames[0], len(frames), vP)          # the timed kernels (sun table, one event visit per collision)
+        assert np.array_equal(buf.download(), ref), est
+        buf.free()
+        assert (ref[..., 3] > 0).mean() > 0.5
+    vp.set_camera()

@@ -183,3 +183,43 @@ def test_truncated_volume_files_are_errors(host, tmp_path):
     L = host.lib()
     assert L.vph_load_raw(cut.encode(), C.c_size_t(8))    # exactly the bytes that are there: fine
     assert not L.vph_load_raw(cut.encode(), C.c_size_t(64))
+
+
+def test_tracked_profiles_agree_with_their_digests():
+    """profiles/: every digest a bench line or DESIGN.md quotes must be reproducible from the rocprofv3 kernel-trace summary
+    tracked next to it (the digests said 513 ms where the tracked CSVs said 629).  For every
+    profiles/rNN_<wl>_digest.json of round 3 on: the CSV of the same name exists, holds the digest's kernel with the same
+    call count and average duration; and profiles/traffic.json points at digests that exist and repeats their numbers."""
+    import csv
+    import glob
+    import json
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    digests = [p for p in glob.glob(os.path.join(prof, "r*_digest.json"))
+               if int(re.match(r"r(\d+)", os.path.basename(p)).group(1)) >= 3]
+    assert digests, "no round-3 digests under profiles/"
+    for dp in digests:
+        d = json.load(open(dp))
+        cp = dp.replace("_digest.json", "_kernel_stats.csv")
+        assert os.path.exists(cp), f"{os.path.basename(dp)} has no kernel_stats.csv beside it"
+        rows = {r["Name"]: r for r in csv.DictReader(open(cp))}
+        for key in ("kernel_trace", "kernel_trace_light"):
+            if key not in d:
+                continue
+            k = d[key]
+            assert k["name"] in rows, (os.path.basename(cp), k["name"])
+            r = rows[k["name"]]
+            assert int(r["Calls"]) == k["calls"]
+            assert abs(float(r["AverageNs"]) / 1e6 - k["avg_ms"]) <= 1e-6 * k["avg_ms"]
+            assert abs(float(r["TotalDurationNs"]) / 1e6 - k["total_ms"]) <= 1e-6 * k["total_ms"]
+    traffic = json.load(open(os.path.join(prof, "traffic.json")))
+    for wl, t in traffic.items():
+        src = os.path.join(root, t["source"])
+        assert os.path.exists(src), (wl, t["source"])
+        d = json.load(open(src))
+        assert abs(d["kernel_trace"]["avg_ms"] - t["launch_ms_kernel_trace"]) <= 1e-9 * t["launch_ms_kernel_trace"]
+        assert d["kernel_trace"]["name"] == t["kernel"]
+        assert abs(d["hbm_bytes_per_launch"] - t["hbm_bytes_per_launch"]) <= 1e-9 * t["hbm_bytes_per_launch"]
+        if int(re.match(r"profiles/r(\d+)", t["source"]).group(1)) >= 3:
+            assert os.path.exists(src.replace("_digest.json", "_kernel_stats.csv"))

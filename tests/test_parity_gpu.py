@@ -642,11 +642,12 @@ np.save(%r, buf.download()); print("launches", n)
 
 
 def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path):
-    """bench.py's N>1 path end to end on this one-GPU box (both ranks on GPU 0, reduce over gloo): the
-    2-rank image of frames [0,8) must equal the 1-rank image bit for bit, and the JSON line must be well formed."""
+    """bench.py's N>1 path end to end on this one-GPU box (both ranks on GPU 0, reduce over gloo), started AS TYPED --
+    `python bench.py --gpus 2`, no external torchrun: bench.py starts its ranks as a child process before anything touches the
+    GPU.  The 2-rank image of frames [0,8) must equal the 1-rank image bit for bit, the JSON line must be well formed, and
+    --scaling both adds the fixed-job (strong) measurement to the weak line."""
     import json
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -656,17 +657,19 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path):
     r1 = subprocess.run([sys.executable, bench, "--gpus", "1", "--spp", "8", "--dump-image", one] + common,
                         capture_output=True, text=True, cwd=root)
     assert r1.returncode == 0, r1.stdout + r1.stderr
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, VP_BENCH_REHEARSAL="1")
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                         "--master-addr", "127.0.0.1", "--master-port", str(port), bench, "--gpus", "2", "--spp", "4",
-                         "--dump-image", two] + common, capture_output=True, text=True, cwd=root, env=env)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["VP_BENCH_REHEARSAL"] = "1"
+    r2 = subprocess.run([sys.executable, bench, "--gpus", "2", "--spp", "4", "--scaling", "both", "--dump-image", two] + common,
+                        capture_output=True, text=True, cwd=root, env=env)
     assert r2.returncode == 0, r2.stdout + r2.stderr
     line1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
     line2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     for line, n in ((line1, 1), (line2, 2)):
         assert line["n_gpus"] == n and line["scaling"] == "weak" and line["unit"] == "Msamples/s" and line["value"] > 0
         assert line["config"]["spp_per_step"] == 8 and set(line["roofline"]) >= {"bound", "achieved", "peak", "frac", "traffic"}
+        assert set(line["per_class"]) >= {"general", "light", "misses_box"} and line["per_camera_setup_ms"] > 0
+    assert line2["strong"]["scaling"] == "strong" and line2["strong"]["spp_per_step"] == 4 and line2["strong"]["value"] > 0
+    assert len(line2["ranks"]["kernel_ms"]) == 2
     assert np.array_equal(np.load(one), np.load(two))
 
 
