@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "cuda-volpath_amd"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0  # same guide, chip table: what streaming kernels reach
 # vector-instruction issue peak of the chip: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
 # (= 157.3 TFLOP/s fp32 / 2 flops / 64 lanes, same guide)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
@@ -253,6 +254,10 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
             pmc_src = f"{pmc.get('source')} @ {pmc.get('commit')} (rocprofv3 --pmc passes of `bench.py --workload {workload}`; " \
                       f"fabric-side counters, Infinity-Cache hits included)"
         loaded_per_launch = loaded_bps * samples_rank / launches
+        traffic_gbps = (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None
+        bounded_by = "valu_issue"
+        if traffic_gbps and valu_frac and traffic_gbps / HBM_ACHIEVABLE_GBS > valu_frac:
+            bounded_by = "memory_system (line-granular gathers)"
         out["roofline"] = {
             # bound/achieved/peak/frac: the contract's HBM roofline on the bytes the timed kernels LOAD (the build's own counters,
             # SURVEY section 8d).  The kernel is not bound by bytes: vector-instruction issue and lane utilisation bound it
@@ -260,7 +265,10 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": pmc_src,
             "traffic_over_loaded_bytes": (traffic / loaded_per_launch) if traffic else None,
-            "bounded_by": "valu_issue", "valu_issue_frac": valu_frac, "valu_issue_peak_per_s": VALU_ISSUE_PEAK, "lane_util": lane_util,
+            # what the memory system really moves per second (128-byte lines for 8-byte cells) against the 6.3 TB/s the guide gives
+            # as achievable: the frame-filling 512^3 cloud (c4f) sits near it, the Julia workloads far below
+            "traffic_GBps": traffic_gbps, "traffic_frac_of_achievable_hbm": (traffic_gbps / HBM_ACHIEVABLE_GBS) if traffic_gbps else None,
+            "bounded_by": bounded_by, "valu_issue_frac": valu_frac, "valu_issue_peak_per_s": VALU_ISSUE_PEAK, "lane_util": lane_util,
             "kernel": "vp::render_k (a launch = the general kernel and, beside it on a second stream, the light kernel of the "
                       "pixels whose camera ray meets empty cells only; HIP events from the start of the first to the end of the last)",
             "launch_ms": launch_ms, "launches": launches,
