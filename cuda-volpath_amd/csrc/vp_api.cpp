@@ -59,6 +59,7 @@ struct State
         int         first = 0, count = 0;
         std::vector<unsigned char> key;
     } la[2];
+    hipStream_t ctrl_stream = nullptr; // la_quiesce: tells batches in flight to stop handing out samples
     int         la_prev_n   = 0;      // batch size of the last miss
     int         la_last     = -2;     // frame index of the last render_kernel call
     std::vector<unsigned char> la_key;  // render state of the staged frames / of the last call
@@ -81,7 +82,7 @@ struct State
     unsigned*   d_queue       = nullptr;
     unsigned long long* d_counters = nullptr;
     bool        count       = false;
-    unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS, setup_lanes = VP_SETUP_LANES, light_wait_iters = 0;  // 0 = by estimator
+    unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS, setup_lanes = VP_SETUP_LANES, end_lanes = VP_END_LANES, light_wait_iters = 0;  // 0 = by estimator
     unsigned    blocks_per_cu = 5;  // resident 256-thread workgroups per CU of a kernel that runs alone (the general kernels hold 94-96 vector
                                     // registers: five waves per SIMD)
     bool        use_lds_bounds = true;
@@ -230,6 +231,7 @@ int ensure_device()
     if (knob("VP_WAIT_LANES", 1, 64, v)) G.wait_lanes = (unsigned)v;
     if (knob("VP_WAIT_ITERS", VP_STEPS_PER_PASS, 1 << 20, v)) G.wait_iters = (unsigned)v;
     if (knob("VP_SETUP_LANES", 1, 64, v)) G.setup_lanes = (unsigned)v;
+    if (knob("VP_END_LANES", 1, 64, v)) G.end_lanes = (unsigned)v;
     if (knob("VP_LIGHT_WAIT_ITERS", VP_STEPS_PER_PASS, 1 << 20, v)) G.light_wait_iters = (unsigned)v;
     if (knob("VP_STAGE_MB", 1, 256 << 10, v)) G.max_stage_bytes = (size_t)v << 20;
     if (knob("VP_BLOCKS_PER_CU", 1, 8, v)) G.blocks_per_cu = (unsigned)v;
@@ -773,7 +775,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     L.out = (float4*)d_out;
     L.counters = G.count ? G.d_counters : nullptr;
     L.key0 = G.key0; L.key1 = G.key1;
-    L.wait_lanes = G.wait_lanes; L.wait_iters = G.wait_iters; L.setup_lanes = G.setup_lanes;
+    L.wait_lanes = G.wait_lanes; L.wait_iters = G.wait_iters; L.setup_lanes = G.setup_lanes; L.end_lanes = G.end_lanes;
     if (sh.per_frame == 0) return VP_OK;
     rc = ensure_crawl_table(p, &L.crawl);
     if (rc) return rc;
@@ -979,11 +981,32 @@ void render_key(const Param* p, std::vector<unsigned char>& key)
 // launch per frame.
 int la_quiesce()
 {
+    // Every caller is about to drop the staged frames (a setter, a camera move, new device contents): what the batches still in
+    // flight would render is of no use.  Their sample queues are told that everything is handed out -- the queue heads jump past
+    // any chunk count (0x80000000; a wave that asks gets "band exhausted") -- so the kernels drain the paths already running
+    // and end: a camera move waits a millisecond or two instead of the rest of a 64-frame batch.  Written from a stream of its
+    // own (the batch's stream is busy with the batch); results are discarded, so nothing depends on where the cut falls.
+    bool any = false;
+    for (int si = 0; si < 2; si++)
+        if (G.la[si].stream && G.la[si].done && G.la[si].valid && hipEventQuery(G.la[si].done) == hipErrorNotReady) any = true;
+    (void)hipGetLastError();
+    if (any)
+    {
+        if (!G.ctrl_stream && hipStreamCreateWithFlags(&G.ctrl_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); G.ctrl_stream = nullptr; }
+        if (G.ctrl_stream)
+        {
+            for (int si = 0; si < 2; si++)
+                if (G.la[si].stream && G.la[si].valid)
+                    (void)hipMemsetD32Async((hipDeviceptr_t)(G.d_queue + 2 * kQueueWords * (si + 1)), (int)0x80000000u, 2 * kQueueWords, G.ctrl_stream);
+            (void)hipGetLastError();
+        }
+    }
     for (auto& s : G.la)
     {
         if (s.stream) HIPCHK(hipStreamSynchronize(s.stream));
         s.valid = false;
     }
+    if (any && G.ctrl_stream) HIPCHK(hipStreamSynchronize(G.ctrl_stream));
     return VP_OK;
 }
 int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, const std::vector<unsigned char>& key)
@@ -1241,6 +1264,7 @@ int vp_ctx_destroy(vp_ctx* ctx)
             if (D.aux_stream[i]) { (void)hipStreamSynchronize(D.aux_stream[i]); (void)hipStreamDestroy(D.aux_stream[i]); }
             for (int q = 0; q < 2; q++) if (D.aux_ev[i][q]) (void)hipEventDestroy(D.aux_ev[i][q]);
         }
+        if (D.ctrl_stream) (void)hipStreamDestroy(D.ctrl_stream);
         if (D.d_queue) (void)hipFree(D.d_queue);
         if (D.d_counters) (void)hipFree(D.d_counters);
         if (D.own_stream) (void)hipStreamDestroy(D.own_stream);

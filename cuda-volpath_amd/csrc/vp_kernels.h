@@ -29,6 +29,9 @@
 #endif
 // lanes that must be waiting for a restart-segment set-up before it runs in the middle of a pass (it always runs at the first
 // step of a pass)
+#ifndef VP_END_LANES
+#define VP_END_LANES 4
+#endif
 #ifndef VP_SETUP_LANES
 #define VP_SETUP_LANES 8
 #endif
@@ -79,6 +82,8 @@ struct LaunchDev
     unsigned long long* counters;  // work counters, loop statistics and block tallies (vp_api.cpp kCounterWords) or null
     unsigned key0, key1;    // Philox key
     unsigned wait_lanes, wait_iters;  // inner-loop exit policy (VP_WAIT_LANES / VP_WAIT_ITERS)
+    unsigned end_lanes;     // lanes that must ask for the path-end chain (environment, write, refill) before it runs in a visit (VP_END_LANES;
+                            // it also runs every fourth visit, and whenever no lane of the wave is tracking)
     unsigned setup_lanes;   // lanes that must ask for a segment set-up before it runs mid-pass (VP_SETUP_LANES; 1 = at every step)
     // Counter-based streams: per cell of the volume, the distance (in steps of clip_ds, 0xffff = unknown) beyond which a ray from
     // anywhere in the cell toward the sun meets empty cells only (sun_clip_k); a sun shadow ray ends there.  Null = walk to the end.

@@ -221,6 +221,7 @@ void render_k(SceneDev S, LaunchDev L)
     // the queue this wave draws from: its XCD's first (HW_REG_XCC_ID, bits 3:0), then the others in turn
     unsigned q_cur   = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & (VP_NQUEUES - 1);
     unsigned q_tried = 0;
+    unsigned end_skipped = 0;   // event visits since the path-end chain last ran (wave-uniform)
 
     for (;;)
     {
@@ -472,6 +473,16 @@ void render_k(SceneDev S, LaunchDev L)
             if (LOCAL) inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
             next_segment();
         }
+        // Path ends (environment, write, refill, and the global-majorant set-up of a fresh sample) come one or two lanes at a time:
+        // the ~300 instructions of this chain are not run in every visit for them.  They wait -- an idle lane or two -- until
+        // end_lanes lanes ask, or four visits have passed, or nothing else is left to do in this wave.
+        {
+            const unsigned long long wantm = __ballot(st == EV_BG || st == EV_WRITE || (st == ST_DONE && !exhausted) || (EST == EST_GLOBAL && st == ST_SETUP));
+            const bool fast_any = __ballot(st == ST_TRACK || st == ST_SHADOW || (LOCAL && st == ST_SETUP)) != 0ull;
+            end_skipped++;
+            if (wantm == 0ull || (!LIGHT && fast_any && (unsigned)__popcll(wantm) < L.end_lanes && end_skipped < 4u)) goto ends_done;
+            end_skipped = 0u;
+        }
 #pragma unroll 1
         for (int rep = 0; rep < 4; rep++)
         {
@@ -642,6 +653,7 @@ void render_k(SceneDev S, LaunchDev L)
             // another round only for lanes this loop can serve: idle ones, and new samples that missed the volume
             if (__ballot((st == ST_DONE && !exhausted) || st == EV_BG || st == EV_WRITE) == 0ull) break;
         }
+ends_done:
         if (__ballot(st != ST_DONE || !exhausted) == 0ull) break;  // queue drained and every lane idle
         }
         if (COUNT) { unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) t_slow += t - t_mark; t_mark = t; }
