@@ -298,9 +298,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=WORKLOAD_CHOICES)
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step (weak) / per step (strong)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "both"],
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong", "both"],
                     help="weak: spp * N per step (per-GPU work fixed); strong: spp per step whatever N; both: the weak line with "
-                         "the strong measurement inside it")
+                         "the strong measurement inside it; auto (default): weak at N = 1, both at N > 1 (the fixed-job run costs "
+                         "1/N of a weak step and shows the per-shard tail the weak line hides)")
     ap.add_argument("--rng", default="philox7", choices=["philox", "philox7", "samplerh"],
                     help="philox7 = Philox2x32-7 (default: the fewest rounds Random123 documents as Crush-resistant; oracle parity "
                          "like the others), philox = Philox2x32-10 (the round-1 default, 4-6 %% slower), samplerh = the reference's "
@@ -341,6 +342,8 @@ def main():
     vp.set_stream(stream.cuda_stream)
     ctx = {"rank": rank, "world": world, "dev": dev, "stream": stream, "rehearsal": rehearsal}
 
+    if args.scaling == "auto":
+        args.scaling = "both" if world > 1 else "weak"
     first = "strong" if args.scaling == "strong" else "weak"
     out = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, first)
     strong = None
