@@ -43,6 +43,10 @@
 #define VP_GLOBAL_MIN_WAVES 5  // achromatic global-majorant kernel: waves per SIMD its register budget is held to (six cost three
                                // spilled registers since the collision block also samples the phase function: 1190 vs 1341 Msamples/s on C2)
 #endif
+#ifndef VP_LIGHT_LOCAL_MIN_WAVES
+#define VP_LIGHT_LOCAL_MIN_WAVES 7   // the local-majorant light kernels need 66-68 registers with the Philox2x32-10 and sampler.h streams:
+                                     // eight waves cost three or four spilled registers, seven (72) none
+#endif
 #ifndef VP_LIGHT_STEPS_PER_PASS
 #define VP_LIGHT_STEPS_PER_PASS 16
 #endif

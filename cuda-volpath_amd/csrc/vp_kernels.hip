@@ -139,7 +139,7 @@ template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool 
 // asking for five costs no spill and is +10 % on the reference-table decomposition workload.  The global-majorant
 // kernel fits six waves (80 VGPRs, no spill): +3 % now that the queue order keeps the L2 hit rate above 90 %.
 __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK,
-                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : VP_LIGHT_MIN_WAVES) : MIS || LDSB ? 1 : (EST == EST_GLOBAL && ACH && TRK == 0 ? VP_GLOBAL_MIN_WAVES : 5)))
+                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : (EST != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES)) : MIS || LDSB ? 1 : (EST == EST_GLOBAL && ACH && TRK == 0 ? VP_GLOBAL_MIN_WAVES : (TRK ? 4 : 5))))
 void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
