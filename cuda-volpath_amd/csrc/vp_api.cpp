@@ -56,6 +56,8 @@ struct State
         hipStream_t stream = nullptr;
         hipEvent_t  done = nullptr;   // recorded after the batch's render
         bool        valid = false;
+        bool        touched = false;  // a frame of this batch was handed to the caller while the batch was still running: its add-kernel
+                                      // waits for the WHOLE batch, which must then run to its end (la_quiesce does not cancel it)
         int         first = 0, count = 0;
         std::vector<unsigned char> key;
     } la[2];
@@ -706,6 +708,7 @@ int ensure_pixel_lists(const Param* p, const float4* table, const Shard& sh)
     if (key == G.tiles_key && G.d_tiles) return VP_OK;
     if (la_quiesce()) return VP_E_NODEVICE;   // batches in flight read the old lists
     HIPCHK(hipStreamSynchronize(G.stream));
+    if ((size_t)sh.owned * 64 > (size_t)0xffffffffu) return fail(VP_E_ARG, "image too large for the 32-bit pixel-list index");
     const unsigned nblocks = pixel_list_blocks(sh.owned);
     if (shape_key != G.tiles_shape_key || !G.d_tile_rows)
     {
@@ -981,14 +984,16 @@ void render_key(const Param* p, std::vector<unsigned char>& key)
 // launch per frame.
 int la_quiesce()
 {
-    // Every caller is about to drop the staged frames (a setter, a camera move, new device contents): what the batches still in
-    // flight would render is of no use.  Their sample queues are told that everything is handed out -- the queue heads jump past
+    // Every caller is about to drop the staged frames (a setter, a camera move, new device contents): what a batch still in
+    // flight would render is of no use -- unless a frame of it has already been handed out (its add-kernel sits on the caller's
+    // stream behind the batch's completion event and needs that frame whole: such a batch runs to its end).  Their sample queues are told that everything is handed out -- the queue heads jump past
     // any chunk count (0x80000000; a wave that asks gets "band exhausted") -- so the kernels drain the paths already running
     // and end: a camera move waits a millisecond or two instead of the rest of a 64-frame batch.  Written from a stream of its
     // own (the batch's stream is busy with the batch); results are discarded, so nothing depends on where the cut falls.
     bool any = false;
+    bool cancel[2] = {false, false};
     for (int si = 0; si < 2; si++)
-        if (G.la[si].stream && G.la[si].done && G.la[si].valid && hipEventQuery(G.la[si].done) == hipErrorNotReady) any = true;
+        if (G.la[si].stream && G.la[si].done && G.la[si].valid && !G.la[si].touched && hipEventQuery(G.la[si].done) == hipErrorNotReady) cancel[si] = any = true;
     (void)hipGetLastError();
     if (any)
     {
@@ -996,7 +1001,7 @@ int la_quiesce()
         if (G.ctrl_stream)
         {
             for (int si = 0; si < 2; si++)
-                if (G.la[si].stream && G.la[si].valid)
+                if (cancel[si])
                     (void)hipMemsetD32Async((hipDeviceptr_t)(G.d_queue + 2 * kQueueWords * (si + 1)), (int)0x80000000u, 2 * kQueueWords, G.ctrl_stream);
             (void)hipGetLastError();
         }
@@ -1014,7 +1019,7 @@ int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, c
     auto& s = G.la[si];
     if (!s.stream) HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     if (!s.done) HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-    s.valid = false;
+    s.valid = false; s.touched = false;
     // after everything queued on the caller's stream: uploads the scene depends on, and add-kernels still reading this slot
     hipEvent_t ev = get_event();
     if (!ev) return fail(VP_E_NODEVICE, "hipEventCreate failed");
@@ -1058,6 +1063,7 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
             if (n > 1 && la_render_slot(si ^ 1, d_out, next, n, p, key)) G.la[si ^ 1].valid = false;  // best effort
         }
         // hit: add the staged frame once its batch is rendered
+        if (hipEventQuery(s.done) != hipSuccess) { (void)hipGetLastError(); s.touched = true; }
         HIPCHK(hipStreamWaitEvent(G.stream, s.done, 0));
         LaunchDev L = {};
         memcpy(&L.P, p, sizeof(Param));
