@@ -12,6 +12,10 @@
  *     SURVEY.md section 4; the sun/sky inputs by oracle/_ref (the reference's own Hosek sources
  *     compiled where they lie); the Julia voxeliser by the occupancy figure and the integrator
  *     by the per-sample work counters of SURVEY.md section 6 (statistical pins).
+ *   - pinned since round 3 by an output the reference itself holds: the GEOMETRY chain -- FractalJuliaSet and its voxelisation,
+ *     the volume box, the camera matrix, field of view and pixel-to-ray map, intersectBox -- by the silhouette of the reference's
+ *     own screenshot of the Julia scene (/root/reference/2.jpg -> tests/golden/ref_julia_silhouette.npz, IoU 0.97 at the
+ *     reference's default camera distance; tests/test_oracle_cpu.py).  Not its radiometry (the screenshot's environment is unknown).
  *   - everything else: "parity unpinned" -- a line-by-line restatement citing file:line.
  */
 #ifndef VP_ORACLE_H

@@ -9,6 +9,12 @@ Sources, by authority:
   hosek_ref.npz      outputs of the reference's own Hosek sky sources (oracle/_ref/libhosek_ref.so,
                      built by oracle/Makefile from /root/reference/src/sunsky/hosek where they lie).
   oracle_*.npz       outputs of the CPU oracle (regression vectors for the GPU path; oracle-made).
+  ref_julia_silhouette.npz   the silhouette of the reference's OWN render of its procedural Julia-set scene -- the screenshot
+                     /root/reference/2.jpg, 960x512 = the reference's default window -- as a bit mask (pixels that differ from the
+                     uniform background), and the camera pose recovered for it by tests/golden/fit_julia_pose.py (orbit direction,
+                     roll and pan fitted; the distance held at the reference's default 4.0).  Pins the geometry chain -- Julia
+                     voxeliser, volume box, camera matrix, field of view, pixel-to-ray map, box intersection -- against an output
+                     the reference itself holds.
 """
 import ctypes as C
 import json
@@ -96,8 +102,22 @@ def oracle_renders():
     np.savez_compressed(os.path.join(HERE, "oracle_renders.npz"), **out)
 
 
+def ref_julia_silhouette(pose=None):
+    """tests/golden/ref_julia_silhouette.npz from the reference's screenshot; `pose` = the six numbers fit_julia_pose.py prints
+    (default: keep the pose already stored in the fixture)."""
+    sys.path.insert(0, HERE)
+    import fit_julia_pose as F
+    path = os.path.join(HERE, "ref_julia_silhouette.npz")
+    if pose is None:
+        pose = np.load(path)["pose"]
+    m = F.reference_mask()
+    np.savez_compressed(path, mask_bits=np.packbits(m), shape=np.array(m.shape), pose=np.asarray(pose, np.float64),
+                        camera=np.asarray(F.camera(pose), np.float32), centre=F.CENTRE)
+
+
 if __name__ == "__main__":
     O.build()
     hosek_ref()
     oracle_renders()
+    ref_julia_silhouette()
     print("golden fixtures written to", HERE)
