@@ -15,8 +15,18 @@ for wl in wls:
     d = json.load(open(os.path.join(src, "digest.json")))
     dst = f"profiles/{tag}_{wl}_digest.json"
     shutil.copy(os.path.join(src, "digest.json"), os.path.join(ROOT, dst))
+    # the kernel-trace summary the digest was computed from: gpurun merges every call's files into gpurun_out/, so an earlier
+    # profile of the same tag may lie beside it -- take the one whose render_k row carries the digest's average
+    import csv
+    picked = None
     for ks in glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(ks, os.path.join(ROOT, f"profiles/{tag}_{wl}_kernel_stats.csv"))
+        rows = {r["Name"]: r for r in csv.DictReader(open(ks))}
+        r = rows.get(d["kernel_trace"]["name"])
+        if r and abs(float(r["AverageNs"]) / 1e6 - d["kernel_trace"]["avg_ms"]) <= 1e-6 * d["kernel_trace"]["avg_ms"]:
+            picked = ks
+    if not picked:
+        raise SystemExit(f"{wl}: no kernel_stats.csv under {src}/kt matches the digest")
+    shutil.copy(picked, os.path.join(ROOT, f"profiles/{tag}_{wl}_kernel_stats.csv"))
     sq, tcc, b = d["sq"]["per_launch"], d["tcc"]["per_launch"], d["bench_line_kt"]
     T[wl] = {
         "hbm_bytes_per_launch": d["hbm_bytes_per_launch"],
