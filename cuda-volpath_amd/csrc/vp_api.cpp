@@ -88,6 +88,7 @@ struct State
     unsigned    blocks_per_cu = 5;  // resident 256-thread workgroups per CU of a kernel that runs alone (the general kernels hold 94-96 vector
                                     // registers: five waves per SIMD)
     bool        use_lds_bounds = true;
+    bool        lds_helper  = true;       // one plain workgroup per CU beside the LDS-table kernel (VP_NO_LDS_HELPER=1)
     int         cell_bricks = 0;          // packed cells in 4x4x4 bricks (VP_CELL_BRICKS=1; an A/B knob, see do_init_volume_)
     // where the restart crawl in front of the volume ends, per pixel (crawl_table_k); rebuilt when what it depends on changes
     bool        use_crawl_table = true;
@@ -238,6 +239,7 @@ int ensure_device()
     if (knob("VP_STAGE_MB", 1, 256 << 10, v)) G.max_stage_bytes = (size_t)v << 20;
     if (knob("VP_BLOCKS_PER_CU", 1, 8, v)) G.blocks_per_cu = (unsigned)v;
     if (knob("VP_NO_LDS_BOUNDS", 0, 1, v)) G.use_lds_bounds = v == 0;
+    if (knob("VP_NO_LDS_HELPER", 0, 1, v)) G.lds_helper = v == 0;
     if (knob("VP_CELL_BRICKS", 0, 1, v)) G.cell_bricks = (int)v;
     if (knob("VP_NO_CRAWL_TABLE", 0, 1, v)) G.use_crawl_table = v == 0;
     if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;
@@ -844,8 +846,10 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         hipError_t le = hipSuccess;
         // the fork point of the light kernel's auxiliary stream: BEFORE the general kernel is queued (the two run side by side),
         // after the queue heads are zeroed; an event of its own, created on first use
+        // (the same fork serves the helper workgroups of the LDS-table kernel, below, when no light kernel needs the stream)
+        const bool lds_helper = lds_bounds && G.lds_helper && G.n_general && !(G.n_light && !light_const);
         bool fork_recorded = false;
-        if (G.n_light && G.n_general && !light_const && G.light_overlap)
+        if ((G.n_light && G.n_general && !light_const && G.light_overlap) || lds_helper)
         {
             const int ti = T.index;
             if (!G.aux_ev[ti][0] && hipEventCreateWithFlags(&G.aux_ev[ti][0], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G.aux_ev[ti][0] = nullptr; }
@@ -930,6 +934,24 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                 ClassTimer ct(0, T.stream);
                 launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, G.trk, (int)blocks, T.stream);
                 le = hipGetLastError();
+                // The LDS-table kernel holds 2 x 64 KiB of a CU's LDS with 2 x 512 threads: four waves per SIMD, where the
+                // registers would allow five.  The fifth comes from the SAME kernel without the LDS stage (the brick table read
+                // from global memory), one 256-thread workgroup per CU beside it on the auxiliary stream, drawing from the same
+                // sample queues: a sample is computed by whichever wave takes its chunk, with the same bits.
+                if (lds_helper && ldsb && le == hipSuccess && fork_recorded && blocks >= cap)
+                {
+                    const int ti = T.index;
+                    if (!G.aux_stream[ti] && hipStreamCreateWithFlags(&G.aux_stream[ti], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); G.aux_stream[ti] = nullptr; }
+                    if (!G.aux_ev[ti][1] && hipEventCreateWithFlags(&G.aux_ev[ti][1], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G.aux_ev[ti][1] = nullptr; }
+                    if (G.aux_stream[ti] && G.aux_ev[ti][1] && hipStreamWaitEvent(G.aux_stream[ti], G.aux_ev[ti][0], 0) == hipSuccess)
+                    {
+                        launch_render(S, L, G.est, G.rng, G.quant, G.count, false, G.env_mis, G.trk, G.num_cu, G.aux_stream[ti]);
+                        le = hipGetLastError();
+                        if (le == hipSuccess && (hipEventRecord(G.aux_ev[ti][1], G.aux_stream[ti]) != hipSuccess || hipStreamWaitEvent(T.stream, G.aux_ev[ti][1], 0) != hipSuccess))
+                            le = hipGetLastError();
+                    }
+                    else (void)hipGetLastError();
+                }
                 ct.stop();
             }
         }
