@@ -30,15 +30,17 @@ if ks:
                         "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"])}
 for d in ("fetch", "write", "sq", "tcc"):
     for f in glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True):
-        agg = collections.defaultdict(float); disp = set()
+        agg = collections.defaultdict(float); disp = collections.defaultdict(set)
         for r in csv.DictReader(open(f)):
             v = variant(r["Kernel_Name"])
             if v and not v["count"]:
                 agg[r["Counter_Name"]] += float(r["Counter_Value"])
                 if not v["light"]:
-                    disp.add(r["Dispatch_Id"])
-        n = max(len(disp), 1)
-        res[d] = {"launches": len(disp), "per_launch": {k: v / n for k, v in agg.items()}}
+                    disp[r["Kernel_Name"]].add(r["Dispatch_Id"])
+        # a launch may hold two general kernels (the LDS-table kernel and its helper workgroups without the LDS stage): each is
+        # dispatched once per launch, so the launches are the dispatches of any one of them
+        n = max([len(x) for x in disp.values()] + [1])
+        res[d] = {"launches": n, "per_launch": {k: v / n for k, v in agg.items()}}
 for d in ("kt", "fetch"):
     try:
         line = [l for l in open(f"{out}/bench_{d}.log") if l.startswith("{")][-1]
