@@ -87,6 +87,7 @@ struct State
     unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS, setup_lanes = VP_SETUP_LANES, end_lanes = VP_END_LANES, light_wait_iters = 0;  // 0 = by estimator
     unsigned    blocks_per_cu = 5;  // resident 256-thread workgroups per CU of a kernel that runs alone (the general kernels hold 94-96 vector
                                     // registers: five waves per SIMD)
+    unsigned    chunk_fshift = 0;         // VP_CHUNK_FRAMES_LOG2: a chunk = (256 >> k) pixels x (1 << k) frames (general class)
     bool        use_lds_bounds = true;
     bool        lds_helper  = true;       // one plain workgroup per CU beside the LDS-table kernel (VP_NO_LDS_HELPER=1)
     int         cell_bricks = 0;          // packed cells in 4x4x4 bricks (VP_CELL_BRICKS=1; an A/B knob, see do_init_volume_)
@@ -238,6 +239,7 @@ int ensure_device()
     if (knob("VP_LIGHT_WAIT_ITERS", VP_STEPS_PER_PASS, 1 << 20, v)) G.light_wait_iters = (unsigned)v;
     if (knob("VP_STAGE_MB", 1, 256 << 10, v)) G.max_stage_bytes = (size_t)v << 20;
     if (knob("VP_BLOCKS_PER_CU", 1, 8, v)) G.blocks_per_cu = (unsigned)v;
+    if (knob("VP_CHUNK_FRAMES_LOG2", 0, 8, v)) G.chunk_fshift = (unsigned)v;
     if (knob("VP_NO_LDS_BOUNDS", 0, 1, v)) G.use_lds_bounds = v == 0;
     if (knob("VP_NO_LDS_HELPER", 0, 1, v)) G.lds_helper = v == 0;
     if (knob("VP_CELL_BRICKS", 0, 1, v)) G.cell_bricks = (int)v;
@@ -870,6 +872,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             L.slot_base   = cls ? G.n_general : 0u;
             L.total_items = (unsigned)((size_t)nt * (size_t)f);
             L.queue       = T.queue + (cls ? kQueueWords : 0);
+            // chunks of pixels x frames (general class): only when the frame count is a multiple of the frame block
+            L.chunk_fshift = (!cls && G.chunk_fshift && f % (1 << G.chunk_fshift) == 0) ? G.chunk_fshift : 0u;
             // the pixels of the class split into VP_NQUEUES bands (whole 64-pixel groups, the last band takes the rest)
             for (unsigned q = 0; q <= VP_NQUEUES; q++) L.q_start[q] = q == VP_NQUEUES ? nt : (unsigned)((unsigned long long)(nt / 64u) * q / VP_NQUEUES) * 64u;
             const bool     ldsb = lds_bounds && !cls;

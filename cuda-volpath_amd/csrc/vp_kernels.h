@@ -82,6 +82,7 @@ struct LaunchDev
                             // draw counts (crawl_table_k, local-majorant estimators), [1].x = certified-empty distance from there,
                             // [1].y = pixel class (0 general, 1 the whole chord is certified empty, 2 the ray misses the box)
     unsigned* queue;        // VP_NQUEUES sample-queue heads, VP_QUEUE_STRIDE words apart (zeroed before the launch)
+    unsigned chunk_fshift;  // log2 of the frames a chunk spans (0: a chunk is VP_CHUNK pixels of one frame; 6: four pixels x 64 frames); nframes is a multiple
     unsigned q_start[VP_NQUEUES + 1];  // slot range [q_start[q], q_start[q+1]) of a frame that queue q hands out
     unsigned long long* counters;  // work counters, loop statistics and block tallies (vp_api.cpp kCounterWords) or null
     unsigned key0, key1;    // Philox key

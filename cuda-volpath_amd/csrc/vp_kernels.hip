@@ -215,8 +215,8 @@ void render_k(SceneDev S, LaunchDev L)
     };
 
     const unsigned lane = threadIdx.x & 63u;
-    unsigned chunk_next = 0, chunk_end = 0;  // wave-uniform
-    unsigned chunk_base = 0, chunk_fl = 0, chunk_stage = 0;  // of the current chunk (wave-uniform)
+    unsigned chunk_s = 0, chunk_n = 0;    // next sample of the current chunk, samples in it (wave-uniform)
+    unsigned chunk_q = 0, chunk_f0 = 0;   // its first pixel slot and first frame (wave-uniform)
     bool     queue_empty = false;
     // the queue this wave draws from: its XCD's first (HW_REG_XCC_ID, bits 3:0), then the others in turn
     unsigned q_cur   = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & (VP_NQUEUES - 1);
@@ -528,7 +528,7 @@ void render_k(SceneDev S, LaunchDev L)
                 }
                 st = ST_DONE;
             }
-            // ---- refill finished lanes from the queue.  The wave owns a chunk [chunk_next, chunk_end)
+            // ---- refill finished lanes from the queue.  The wave owns a chunk of samples (chunk_s .. chunk_n)
             // of consecutive samples (one atomic per VP_CHUNK samples); idle lanes are compacted
             // with ballot + mbcnt and take the next samples of the chunk.
             {
@@ -537,29 +537,30 @@ void render_k(SceneDev S, LaunchDev L)
                 tally(B_REFILL, need);
                 if (m)
                 {
-                    while (chunk_next >= chunk_end && !queue_empty)
+                    while (chunk_s >= chunk_n && !queue_empty)
                     {
                         // queue q_cur: chunk c is frame (c % nframes) of chunk position (c / nframes) of its band -- the waves
                         // running at the same time work on the same few tiles in different frames, i.e. on rays through the
                         // same pencil of the volume
+                        // A chunk is (VP_CHUNK >> chunk_fshift) consecutive pixels of the band x (1 << chunk_fshift) consecutive frames
+                        // (the host sets chunk_fshift = 0 unless the frame count is a multiple): sample s of it is pixel s >> shift,
+                        // frame s & mask -- with shift 6 a wave starts on ONE pixel in 64 frames: the same camera ray in every lane.
                         const unsigned q0 = L.q_start[q_cur], len = L.q_start[q_cur + 1] - q0;
-                        const unsigned cpf = (len + (unsigned)VP_CHUNK - 1) / (unsigned)VP_CHUNK;
+                        const unsigned sh = L.chunk_fshift, ppc = (unsigned)VP_CHUNK >> sh, fblocks = (unsigned)L.nframes >> sh;
+                        const unsigned cpf = (len + ppc - 1u) / ppc;
                         unsigned c = 0xffffffffu;
                         if (len)
                         {
                             if (lane == 0) c = atomicAdd(L.queue + q_cur * VP_QUEUE_STRIDE, 1u);
                             c = __builtin_amdgcn_readfirstlane(c);
                         }
-                        if (c < cpf * (unsigned)L.nframes)
+                        if (c < cpf * fblocks)
                         {
-                            const unsigned pos = c / (unsigned)L.nframes, fl = c - pos * (unsigned)L.nframes, off = pos * (unsigned)VP_CHUNK;
-                            chunk_base = fl * (L.nslots);
-                            chunk_next = chunk_base + q0 + off;
-                            chunk_end  = chunk_next + (len - off < (unsigned)VP_CHUNK ? len - off : (unsigned)VP_CHUNK);
-                            // the chunk lies in ONE frame: its frame and where that frame's samples of this class start in the
-                            // staging buffer are found once here (no integer division per lane in a refill)
-                            chunk_fl    = fl;
-                            chunk_stage = fl * L.stage_stride + L.slot_base;
+                            const unsigned pos = c / fblocks, fb = c - pos * fblocks, off = pos * ppc;
+                            chunk_q  = q0 + off;
+                            chunk_f0 = fb << sh;
+                            chunk_n  = (len - off < ppc ? len - off : ppc) << sh;
+                            chunk_s  = 0;
                         }
                         else
                         {
@@ -569,7 +570,7 @@ void render_k(SceneDev S, LaunchDev L)
                         }
                     }
                     unsigned cnt   = (unsigned)__popcll(m);
-                    unsigned avail = chunk_end - chunk_next;
+                    unsigned avail = chunk_n - chunk_s;
                     unsigned take  = cnt < avail ? cnt : avail;
                     unsigned rank  = lane_rank(m);
                     if (need)
@@ -577,12 +578,14 @@ void render_k(SceneDev S, LaunchDev L)
                         if (rank >= take) { if (queue_empty) exhausted = true; /* else: next chunk, next round */ }
                         else
                         {
-                            unsigned rem = chunk_next + rank - chunk_base;  // sample slot of this class within the frame
-                            item = chunk_stage + rem;
+                            const unsigned sn  = chunk_s + rank, sh = L.chunk_fshift;
+                            const unsigned rem = chunk_q + (sn >> sh);              // sample slot of this class within the frame
+                            const unsigned fl  = chunk_f0 + (sn & ((1u << sh) - 1u));
+                            item = fl * L.stage_stride + L.slot_base + rem;
                             unsigned pix = L.pixels[rem];
                             px    = pix & 0xffffu;
                             py    = pix >> 16;
-                            frame = L.frame0 + (int)chunk_fl;
+                            frame = L.frame0 + (int)fl;
                             if (px < P.width && py < P.height)
                             {
                                 // camera ray, kernel.cu:1977-1987 (quirk Q3)
@@ -617,7 +620,7 @@ void render_k(SceneDev S, LaunchDev L)
                             // pixels of a partial edge tile outside the image: nothing to do, stay DONE
                         }
                     }
-                    chunk_next += take;
+                    chunk_s += take;
                 }
             }
             // ---- global-majorant segment set-up (__d_render kernel.cu:1332-1370); rare, so it lives here
