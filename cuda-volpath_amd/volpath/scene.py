@@ -40,6 +40,11 @@ WORKLOADS = {
     "c4f": dict(n=512, width=1280, height=720, est=EST_DECOMP, brick=16, chromatic=True, volume="cloud", seed=1,
                 camera_pose=((2.0, 0.35, 0.25), (-0.97, -0.17, -0.12), (0.0, 1.0, 0.0)),
                 name="STANDIN_fbmcloud512_framefilling_1280x720_chromatic_decomp_brick16"),
+    # the same cloud at 256^3 (cells 134 MB: inside the 256 MiB Infinity Cache, where the 512^3 cells, 1.07 GB, are not): what c4f's
+    # memory traffic costs, measured as the difference between the two (development workload, not a bench line)
+    "c4f256": dict(n=256, width=1280, height=720, est=EST_DECOMP, brick=8, chromatic=True, volume="cloud", seed=1,
+                   camera_pose=((2.0, 0.35, 0.25), (-0.97, -0.17, -0.12), (0.0, 1.0, 0.0)),
+                   name="STANDIN_fbmcloud256_framefilling_1280x720_chromatic_decomp_brick8"),
 }
 
 
