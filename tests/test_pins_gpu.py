@@ -456,58 +456,69 @@ def test_pixel_table_certificates_hold_in_float64(vp, est):
     assert (t_left[hit] > 0).mean() > 0.8 and (cls[hit] == 1).mean() > 0.3
 
 
+@pytest.mark.parametrize("kind", ["julia", "ragged"])
 @pytest.mark.parametrize("sun", [(-0.0, 0.951057, -0.309017), (0.6, -0.3, 0.74), (0.0, 0.0, -1.0)])
-def test_sun_clip_certificate_holds_in_float64(vp, sun):
+def test_sun_clip_certificate_holds_in_float64(vp, sun, kind):
     """Counter-based streams end a sun shadow ray where it has only empty cells left (vp_kernels.hip sun_clip_k).  The table is
     a claim about geometry, checked here in float64 against the raw volume, without the oracle: from random start points in
     random non-empty cells, every point of the ray toward the sun beyond table[cell] * step lies in a cell whose 2x2x2 texels
-    are all zero.  Also: every non-empty cell has an entry, empty cells are marked unknown, and the table is not vacuous."""
+    are all zero.  Also: every non-empty cell has an entry, empty cells are marked unknown, and the table is not vacuous.
+    `ragged`: a non-cubic grid in an off-centre, non-cubic box (cells of different edge lengths per axis)."""
     import scenes
     rng = np.random.default_rng(11)
-    n = 48
-    grid = vp.julia_volume(n)
-    vp.init_volume(grid, brick=1, linear=True)
+    if kind == "julia":
+        grid = vp.julia_volume(48)
+        bmin, bmax = np.array([-1.0, -1.0, -1.0]), np.array([1.0, 1.0, 1.0])
+        vp.init_volume(grid, brick=1, linear=True)
+    else:
+        g = scenes.blob_volume_u8(28, seed=5)[:20, :, :]
+        grid = np.ascontiguousarray(np.pad(g, ((0, 0), (0, 0), (0, 8)))[:, :28, :36])      # nz, ny, nx = 20, 28, 36
+        bmin, bmax = np.array([-0.7, -1.3, 0.1]), np.array([1.6, 0.2, 1.4])
+        vp.init_volume(grid, box=(tuple(bmin), tuple(bmax)), brick=1, linear=True)
+    nz, ny, nx = grid.shape
+    N = np.array([nx, ny, nz], np.float64)
     vp.init_envmap(scenes.synthetic_env())
     sun = np.asarray(sun, np.float64) / np.linalg.norm(sun)
     vp.set_sun(tuple(sun), scenes.DEFAULT_SUN_POWER)
     vp.set_camera()
     vp.set_rng(vp.RNG_PHILOX7, (1, 2))
-    table, step = vp.sun_clip_table((n, n, n))
-    assert abs(step - 0.25 * 2.0 / n) < 1e-7
+    table, step = vp.sun_clip_table((nz, ny, nx))
+    cell_edges = (bmax - bmin) / N
+    assert abs(step - 0.25 * cell_edges.min()) < 1e-6
     g = np.pad(grid, ((0, 1), (0, 1), (0, 1)), mode="edge") != 0
-    cell_nonempty = np.zeros((n, n, n), bool)
+    cell_nonempty = np.zeros((nz, ny, nx), bool)
     for dz in (0, 1):
         for dy in (0, 1):
             for dx in (0, 1):
-                cell_nonempty |= g[dz:dz + n, dy:dy + n, dx:dx + n]
+                cell_nonempty |= g[dz:dz + nz, dy:dy + ny, dx:dx + nx]
     assert np.array_equal(table == 0xffff, ~cell_nonempty)
     ks, js, is_ = np.nonzero(cell_nonempty)
-    pick = rng.choice(len(ks), 600, replace=False)
-    cell = 2.0 / n
+    pick = rng.choice(len(ks), min(600, len(ks)), replace=False)
     checked = 0
     for k, j, i in zip(ks[pick], js[pick], is_[pick]):
         # a random point of the cell in continuous cell coordinates xb = p * N - 0.5 (cell 0 also takes xb in [-0.5, 0), the last
         # cell ends at N - 0.5), as a world position
-        lo = np.array([-0.5 if c == 0 else c for c in (i, j, k)], np.float64)
-        hi = np.array([n - 0.5 if c == n - 1 else c + 1 for c in (i, j, k)], np.float64)
+        c = np.array([i, j, k])
+        lo = np.where(c == 0, -0.5, c.astype(np.float64))
+        hi = np.where(c == N - 1, N - 0.5, c + 1.0)
         xb = lo + (hi - lo) * rng.random(3)
-        p0 = (xb + 0.5) / n * 2.0 - 1.0
+        p0 = bmin + (xb + 0.5) / N * (bmax - bmin)
         t0 = float(table[k, j, i]) * step
-        # to the box exit (slab test), sampled at 1/20 cell
-        with np.errstate(divide="ignore"):
-            tt = np.where(sun > 0, (1.0 - p0) / sun, np.where(sun < 0, (-1.0 - p0) / sun, np.inf))
+        # to the box exit (slab test), sampled at 1/20 of the smallest cell edge
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tt = np.where(sun > 0, (bmax - p0) / sun, np.where(sun < 0, (bmin - p0) / sun, np.inf))
         t1 = float(tt.min())
         if t1 <= t0:
             continue
-        ts = np.arange(t0, t1, cell / 20)
-        q = (p0 + sun * ts[:, None] + 1.0) / 2.0 * n - 0.5
-        idx = np.clip(np.floor(np.maximum(q, 0)).astype(int), 0, n - 1)
+        ts = np.arange(t0, t1, cell_edges.min() / 20)
+        q = ((p0 + sun * ts[:, None]) - bmin) / (bmax - bmin) * N - 0.5
+        idx = np.clip(np.floor(np.maximum(q, 0)).astype(int), 0, (N - 1).astype(int))
         assert not cell_nonempty[idx[:, 2], idx[:, 1], idx[:, 0]].any(), (k, j, i)
         checked += len(ts)
-    assert checked > 50000
+    assert checked > (50000 if kind == "julia" else 5000)
     # not vacuous: some of the non-empty cells see the sun within a few cells, and on average a ray ends well before the box does
-    assert (table[cell_nonempty] * step < 4 * cell).mean() > 0.04
-    assert (table[cell_nonempty] * step).mean() < 1.0
+    assert (table[cell_nonempty] * step < 4 * cell_edges.max()).mean() > 0.04
+    assert (table[cell_nonempty] * step).mean() < 0.5 * np.linalg.norm(bmax - bmin)
 
 
 def test_shadow_rays_draw_from_their_own_substream(vp):
