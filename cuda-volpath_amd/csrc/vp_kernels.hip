@@ -5,10 +5,13 @@
 // its neighbours keep tracking; every path carries its own RNG state and therefore computes the
 // same bits wherever and whenever it runs.  A wave alternates between an inner loop of free-flight
 // steps (four per pass; segment set-up included for the local-majorant estimators) and an event
-// pass that serves the lanes parked on collisions, light estimates, exits and refills.  What depends on a pixel's camera
+// pass that serves the lanes parked on collisions, exits and refills.  With the counter-based streams a collision takes ONE
+// visit (shadow rays draw from sub-streams: the phase function is sampled in the collision block, the light is added where the
+// shadow ray ends) and a sun shadow ray ends where only empty cells are left (sun_clip_k).  What depends on a pixel's camera
 // ray alone (the same ray in every frame) is tabulated once per pixel -- the restart crawl in front of the volume, the
 // distance up to which the ray meets only empty cells, the pixel's class -- and pixels whose ray never meets a non-empty
-// cell run the LIGHT specialisation of the kernel beside the general one (crawl_table_k, empty_table_k).
+// cell are per-pixel constants where a null collision in empty space leaves the throughput at exactly 1 (light_identity_k,
+// miss_fill_k), else they run the LIGHT specialisation of the kernel beside the general one.
 // Restates
 //   __d_render_bounded_decomp  kernel.cu:1958-2318  (EST_DECOMP, the reference's live kernel)
 //   __d_render                 kernel.cu:1285-1591  (EST_GLOBAL, BASELINE config 2)
@@ -137,7 +140,8 @@ __global__ void light_identity_k(ParamDev P, int local, const unsigned* mask, un
 template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool MIS, int TRK, bool LIGHT = false>
 // The local-majorant kernels need 98 VGPRs when left alone, two more than five waves per SIMD allow (512 / 5 -> 96):
 // asking for five costs no spill and is +10 % on the reference-table decomposition workload.  The global-majorant
-// kernel fits six waves (80 VGPRs, no spill): +3 % now that the queue order keeps the L2 hit rate above 90 %.
+// kernel runs five as well (88 registers): six (80) cost three spilled registers since its collision block also samples the
+// phase function and prepares the next segment (1190 vs 1341 Msamples/s on C2); profiles/r03_kernel_resources.txt.
 __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK,
                              (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : (EST != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES)) : MIS || LDSB ? 1 : (EST == EST_GLOBAL && ACH && TRK == 0 ? VP_GLOBAL_MIN_WAVES : (TRK ? 4 : 5))))
 void render_k(SceneDev S, LaunchDev L)
