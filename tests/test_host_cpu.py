@@ -223,3 +223,22 @@ def test_tracked_profiles_agree_with_their_digests():
         assert abs(d["hbm_bytes_per_launch"] - t["hbm_bytes_per_launch"]) <= 1e-9 * t["hbm_bytes_per_launch"]
         if int(re.match(r"profiles/r(\d+)", t["source"]).group(1)) >= 3:
             assert os.path.exists(src.replace("_digest.json", "_kernel_stats.csv"))
+
+
+def test_output_stage_reproduces_the_background_of_the_references_screenshots(host, tmp_path):
+    """A small radiometric pin the reference holds: the background colours of its two screenshots.  A camera ray that misses the
+    volume shows the environment unchanged (background(), kernel.cu:1258-1267), the host scales by 1/spp, applies gamma 2.2
+    (gamma_correct, kernel.cu:2348-2362, host.cpp:384) and the frame goes to 8 bits.  The environment of that build is still in
+    the source as a disabled branch (host.cpp:1374-1385: rows (0.03, 0.07, 0.23) above (0.03, 0.03, 0.03)); 1.jpg's background is
+    (53, 75, 132) and 2.jpg's (52, 52, 52) -- the medians of the two JPEGs, recorded here.  This library's output stage (Image:
+    tonemap_gamma + 8-bit PPM) must turn those radiances into those colours, within JPEG's error."""
+    for radiance, seen in (((0.03, 0.07, 0.23), (53, 75, 132)), ((0.03, 0.03, 0.03), (52, 52, 52))):
+        img = np.zeros((4, 6, 4), np.float32)
+        img[..., :3] = radiance
+        img[..., 3] = 1.0
+        path = str(tmp_path / "bg.ppm")
+        host.write_image(img, path, hdr=False, tonemap=1, gamma=2.2, scale=1.0)
+        raw = open(path, "rb").read()
+        px = np.frombuffer(raw[-4 * 6 * 3:], np.uint8).reshape(4, 6, 3)
+        assert np.all(px == px[0, 0])
+        assert np.abs(px[0, 0].astype(int) - np.array(seen)).max() <= 2, (px[0, 0], seen)
