@@ -555,3 +555,72 @@ def test_cloud_workload_is_bit_exact_at_reduced_size(vp, oracle, tmp_path):
         buf.free()
         assert (ref[..., 3] > 0).mean() > 0.5
     vp.set_camera()
+
+
+@pytest.mark.parametrize("est,brick", [(0, 1), (1, 8), (1, 1)])
+def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
+    """"results never depend on the knobs".  A context reads the VP_* environment when it is created:
+    contexts created under different settings -- tables, sun table, constant light class, light kernel, helper workgroups, LDS
+    stage, cell order, chunk shape, wait / set-up / end policies, one staged frame per launch -- render the same bits as the
+    default context, which in turn equals the oracle."""
+    W, H = 96, 64
+    grid = oracle.julia(64)
+    env = scenes.synthetic_env()
+    frames = range(8, 14)                       # across the frame-11 switch of the live kernel
+
+    def scene():
+        vp.init_volume(grid, brick=brick, linear=True)
+        vp.init_envmap(env)
+        vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+        vp.set_camera()
+        vp.set_estimator(est)
+        vp.set_tracking(0)
+        vp.set_rng(vp.RNG_PHILOX7, (4, 2))
+        vp.set_shard(0, 1)
+        if est == 1:
+            vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+
+    def render():
+        P = vp.make_param(W, H)
+        buf = vp.DeviceBuffer(W, H)
+        vp.render_frames(buf.ptr, frames[0], len(frames), P)
+        out = buf.download()
+        buf.free()
+        return out
+
+    scene()
+    want = render()
+    osc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, brick=brick, estimator=est,
+                             rng_mode=oracle.RNG_PHILOX7, seed=(4, 2))
+    if est == 1:
+        osc.precompute_opacity()
+    ref, oP = None, oracle.default_param(W, H)
+    for f in frames:
+        ref, _ = osc.render_frame(oP, f, ref)
+    assert np.array_equal(want, ref)
+    settings = [
+        dict(VP_NO_SUN_CLIP="1"), dict(VP_NO_LIGHT_CONST="1"), dict(VP_NO_LIGHT="1"), dict(VP_NO_CRAWL_TABLE="1", VP_NO_EMPTY_TABLE="1"),
+        dict(VP_NO_LDS_HELPER="1"), dict(VP_NO_LDS_BOUNDS="1"), dict(VP_CELL_BRICKS="1"), dict(VP_CHUNK_FRAMES_LOG2="1"),
+        dict(VP_WAIT_LANES="5", VP_WAIT_ITERS="4", VP_SETUP_LANES="1", VP_END_LANES="1"), dict(VP_END_LANES="40", VP_SETUP_LANES="33"),
+        dict(VP_STAGE_MB="1", VP_BLOCKS_PER_CU="2"), dict(VP_NO_LIGHT_OVERLAP="1", VP_NO_LIGHT_CONST="1"),
+    ]
+    for env_set in settings:
+        saved = {k: os.environ.get(k) for k in env_set}
+        os.environ.update(env_set)
+        try:
+            ctx = vp.Context(0)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        try:
+            with ctx:
+                scene()
+                got = render()
+        finally:
+            ctx.destroy()
+        assert np.array_equal(got, want), env_set
+    scene()                                     # the default context is untouched by all of it
+    assert np.array_equal(render(), want)
