@@ -624,3 +624,56 @@ def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
         assert np.array_equal(got, want), env_set
     scene()                                     # the default context is untouched by all of it
     assert np.array_equal(render(), want)
+
+
+@pytest.mark.parametrize("workload,first", [("c2", 0), ("c3", 0), ("c4s", 0), ("c4f", 0), ("c3", 9), ("c4f", 9)])
+def test_full_size_workloads_match_the_oracle_on_sampled_pixels(vp, oracle, workload, first):
+    """The bench workloads AT FULL SIZE -- BASELINE configs[1] and [2] (Julia-256^3, 800x600) and the two 512^3 / 1280x720 chromatic
+    stand-ins of configs[3] (Julia and the frame-filling cloud through the dense-dump ingest path), the baked Hosek sky, the bench's
+    Philox2x32-7 streams -- against the oracle pixel by pixel on a sample of the image: up to 1200 pixels that scatter, 300 whose
+    ray meets empty cells only and 300 that miss the box, four frames, tolerance 0.  (The whole-image comparisons stop at 120x56
+    and 64^3; the oracle takes a quarter of an hour per full-size frame.)  first = 9: frames 9..12, across the live kernel's
+    switch to the optical-depth table at frame 11 (quirk Q5); the oracle's N^4 precompute of that table is not affordable at these
+    sizes, so it reads the table the GPU built -- itself compared with the oracle's at 32^3 in test_parity_gpu.py."""
+    import ctypes as C
+    from volpath import scene as vscene
+    cfg = vscene.WORKLOADS[workload]
+    P, info = vscene.setup(workload, rng_mode=vp.RNG_PHILOX7, key=(0x9E3779B9, 0x85EBCA6B), last_frame=first + 4)
+    W, H, frames = P.width, P.height, 4
+    buf = vp.DeviceBuffer(W, H)
+    vp.render_frames(buf.ptr, first, frames, P)
+    got = buf.download()
+    buf.free()
+    cls = vp.pixel_table(P)[..., 5].astype(int)
+    rng = np.random.default_rng(5)
+    pick = []
+    for c, n in ((0, 1200), (1, 300), (2, 300)):
+        ys, xs = np.nonzero(cls == c)
+        if len(ys):
+            sel = rng.choice(len(ys), min(n, len(ys)), replace=False)
+            pick += list(zip(ys[sel], xs[sel]))
+    env, sun_dir, sun_power = info["sunsky"]
+    grid = vscene.host_volume(workload)
+    osc = oracle.OracleScene(grid, env, sun_dir, sun_power, brick=cfg["brick"], estimator=cfg["est"], rng_mode=oracle.RNG_PHILOX7,
+                             seed=(0x9E3779B9, 0x85EBCA6B), inv_view=vscene.camera_of(cfg))
+    oP = oracle.default_param(W, H)
+    if cfg["chromatic"]:
+        oracle.mat(oP, *scenes.PRESET1)
+    if first + frames > 11 and cfg["est"] == oracle.EST_DECOMP:
+        n = cfg["n"]
+        osc.opacity = vp.opacity_table((n, n, n))
+        osc.S.opacity = osc.opacity.ctypes.data
+    L = oracle.lib()
+    out = (C.c_float * 4)()
+    cnt = oracle.Counters()
+    bad = 0
+    for y, x in pick:
+        acc = np.zeros(4, np.float32)
+        for f in range(first, first + frames):
+            L.vpo_render_sample(C.byref(osc.S), C.byref(oP), int(x), int(y), f, out, C.byref(cnt))
+            acc = acc + np.array(out[:], np.float32)
+        if not np.array_equal(acc, got[y, x]):
+            bad += 1
+    assert bad == 0, f"{bad} of {len(pick)} sampled pixels differ"
+    assert (got[..., 3] > 0).mean() > 0.05
+    vp.set_camera()
