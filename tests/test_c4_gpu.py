@@ -626,19 +626,22 @@ def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
     assert np.array_equal(render(), want)
 
 
-@pytest.mark.parametrize("workload,first", [("c2", 0), ("c3", 0), ("c4s", 0), ("c4f", 0), ("c3", 9), ("c4f", 9)])
-def test_full_size_workloads_match_the_oracle_on_sampled_pixels(vp, oracle, workload, first):
+@pytest.mark.parametrize("workload,first,rng_mode", [("c2", 0, 2), ("c3", 0, 2), ("c4s", 0, 2), ("c4f", 0, 2), ("c3", 9, 2), ("c4f", 9, 2),
+                                                     ("c3ref", 0, 0), ("c3ref", 9, 0), ("c2", 0, 0)])
+def test_full_size_workloads_match_the_oracle_on_sampled_pixels(vp, oracle, workload, first, rng_mode):
     """The bench workloads AT FULL SIZE -- BASELINE configs[1] and [2] (Julia-256^3, 800x600) and the two 512^3 / 1280x720 chromatic
     stand-ins of configs[3] (Julia and the frame-filling cloud through the dense-dump ingest path), the baked Hosek sky, the bench's
     Philox2x32-7 streams -- against the oracle pixel by pixel on a sample of the image: up to 1200 pixels that scatter, 300 whose
     ray meets empty cells only and 300 that miss the box, four frames, tolerance 0.  (The whole-image comparisons stop at 120x56
     and 64^3; the oracle takes a quarter of an hour per full-size frame.)  first = 9: frames 9..12, across the live kernel's
     switch to the optical-depth table at frame 11 (quirk Q5); the oracle's N^4 precompute of that table is not affordable at these
-    sizes, so it reads the table the GPU built -- itself compared with the oracle's at 32^3 in test_parity_gpu.py."""
+    sizes, so it reads the table the GPU built -- itself compared with the oracle's at 32^3 in test_parity_gpu.py.
+    rng_mode 0: the reference's own sampler.h streams, on c3ref = the reference's live configuration (its estimator, its per-voxel
+    bound table, its default scene and window-independent camera) -- what a run of the reference itself computes, sample by sample."""
     import ctypes as C
     from volpath import scene as vscene
     cfg = vscene.WORKLOADS[workload]
-    P, info = vscene.setup(workload, rng_mode=vp.RNG_PHILOX7, key=(0x9E3779B9, 0x85EBCA6B), last_frame=first + 4)
+    P, info = vscene.setup(workload, rng_mode=rng_mode, key=(0x9E3779B9, 0x85EBCA6B), last_frame=first + 4)
     W, H, frames = P.width, P.height, 4
     buf = vp.DeviceBuffer(W, H)
     vp.render_frames(buf.ptr, first, frames, P)
@@ -654,7 +657,7 @@ def test_full_size_workloads_match_the_oracle_on_sampled_pixels(vp, oracle, work
             pick += list(zip(ys[sel], xs[sel]))
     env, sun_dir, sun_power = info["sunsky"]
     grid = vscene.host_volume(workload)
-    osc = oracle.OracleScene(grid, env, sun_dir, sun_power, brick=cfg["brick"], estimator=cfg["est"], rng_mode=oracle.RNG_PHILOX7,
+    osc = oracle.OracleScene(grid, env, sun_dir, sun_power, brick=cfg["brick"], estimator=cfg["est"], rng_mode=rng_mode,
                              seed=(0x9E3779B9, 0x85EBCA6B), inv_view=vscene.camera_of(cfg))
     oP = oracle.default_param(W, H)
     if cfg["chromatic"]:
