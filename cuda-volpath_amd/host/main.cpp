@@ -26,6 +26,8 @@ static void usage()
            "               [--sun X Y] [--batch F] [--out name(.ppm|.hdr)]\n"
            "               [--gpus N [--devices a,b,...]]   N contexts, pixel tiles dealt by vp_set_shard, one RCCL reduce;\n"
            "                                                a repeated device (e.g. --gpus 2 --devices 0,0) shares one GPU\n"
+           "                                                (distinct devices: the RCCL path has run with one rank only so far -- UNVERIFIED\n"
+           "                                                between GPUs; --rccl-selftest checks that RCCL loads and reduces here)\n"
            "               [--rccl-selftest [device]]       load RCCL, one-rank communicator, one reduce: the calls of the N > 1 path\n");
 }
 
