@@ -21,7 +21,7 @@
 static void usage()
 {
     printf("volpath_render [--julia N | --bin file.bin | --vdb file.vdb] [--size W H] [--spp N] [--preset 0..12]\n"
-           "               [--density D] [--g G] [--estimator decomp|global|bounded] [--brick B] [--rng samplerh|philox]\n"
+           "               [--density D] [--g G] [--estimator decomp|global|bounded] [--brick B] [--rng samplerh|philox|philox7]\n"
            "               [--tracking spectral|scalar|multichannel] [--env passive|mis]\n"
            "               [--sun X Y] [--batch F] [--out name(.ppm|.hdr)]\n"
            "               [--gpus N [--devices a,b,...]]   N contexts, pixel tiles dealt by vp_set_shard, one RCCL reduce;\n"
@@ -35,7 +35,7 @@ int main(int argc, char** argv)
 {
     int         julia = 128, W = 400, H = 300, spp = 16, preset = 12, brick = 1, batch = 0;
     float       density = 800.0f, g = 0.877f, sunx = 0.5f, suny = 0.2f;
-    bool        philox = false;
+    int         philox = 0;   // 0 sampler.h, 1 Philox2x32-10, 2 Philox2x32-7
     int         est = VP_EST_DECOMP, tracking = VP_TRACK_SPECTRAL, env_mode = VP_ENV_PASSIVE;
     std::string bin, vdb, out = "output0.ppm", devlist;
     int         gpus = 1;
@@ -58,7 +58,7 @@ int main(int argc, char** argv)
             est = !strcmp(e, "global") ? VP_EST_GLOBAL : !strcmp(e, "bounded") ? VP_EST_BOUNDED : VP_EST_DECOMP;
         }
         else if (a == "--brick") { need(1); brick = atoi(argv[++i]); }
-        else if (a == "--rng") { need(1); philox = !strcmp(argv[++i], "philox"); }
+        else if (a == "--rng") { need(1); ++i; philox = !strcmp(argv[i], "philox") ? 1 : !strcmp(argv[i], "philox7") ? 2 : 0; }
         else if (a == "--tracking")
         {
             need(1);
@@ -149,7 +149,7 @@ int main(int argc, char** argv)
         set_sun(&sky.sun_dir.x, &sky.sun_power.x);
         vp_set_estimator(est);
         if (vp_set_tracking(tracking) || vp_set_envmap_sampling(env_mode) || vp_set_shard(r, gpus)) { fprintf(stderr, "%s\n", vp_last_error()); return 1; }
-        vp_set_rng(philox ? VP_RNG_PHILOX : VP_RNG_SAMPLERH, 0x9E3779B9u, 0x85EBCA6Bu);
+        vp_set_rng(philox == 2 ? VP_RNG_PHILOX7 : philox ? VP_RNG_PHILOX : VP_RNG_SAMPLERH, 0x9E3779B9u, 0x85EBCA6Bu);
         // frame buffer (CudaFrameBuffer host.cpp:358-389), full frame on every rank: zero outside its tiles
         accum[r] = (vp_float4*)vp_malloc((size_t)npix * sizeof(vp_float4));
         if (!accum[r]) { fprintf(stderr, "%s\n", vp_last_error()); return 1; }
