@@ -62,6 +62,7 @@ struct State
         std::vector<unsigned char> key;
     } la[2];
     hipStream_t ctrl_stream = nullptr; // la_quiesce: tells batches in flight to stop handing out samples
+    bool        la_cancel   = true;    // VP_NO_LA_CANCEL=1: batches in flight always run to their end
     int         la_prev_n   = 0;      // batch size of the last miss
     int         la_last     = -2;     // frame index of the last render_kernel call
     std::vector<unsigned char> la_key;  // render state of the staged frames / of the last call
@@ -255,6 +256,7 @@ int ensure_device()
     if (knob("VP_LIGHT_BLOCKS_PER_CU", 1, 8, v)) G.light_blocks_per_cu = (unsigned)v;
     if (knob("VP_THR_TABLE", 2, 1 << 20, v)) G.thr_entries = (unsigned)v;
     if (knob("VP_LOOKAHEAD", 0, 4096, v)) G.la_max = (int)v;
+    if (knob("VP_NO_LA_CANCEL", 0, 1, v)) G.la_cancel = v == 0;
     G.dev_ready = true;
     return VP_OK;
 }
@@ -1018,7 +1020,7 @@ int la_quiesce()
     // own (the batch's stream is busy with the batch); results are discarded, so nothing depends on where the cut falls.
     bool any = false;
     bool cancel[2] = {false, false};
-    for (int si = 0; si < 2; si++)
+    for (int si = 0; si < 2 && G.la_cancel; si++)
         if (G.la[si].stream && G.la[si].done && G.la[si].valid && !G.la[si].touched && hipEventQuery(G.la[si].done) == hipErrorNotReady) cancel[si] = any = true;
     (void)hipGetLastError();
     if (any)
@@ -1045,7 +1047,13 @@ int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, c
     auto& s = G.la[si];
     if (!s.stream) HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     if (!s.done) HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-    s.valid = false; s.touched = false;
+    s.valid = false;
+    // `touched` guards the batch that is being replaced as well: it may still be running on this stream (a miss invalidates a slot
+    // without waiting for it) and shares the slot's sample queues with the new one, so a cancel aimed at the new batch would cut
+    // the old one short -- while an add-kernel for one of its frames may still be pending.  The mark is dropped only once the old
+    // batch has completed.
+    if (!s.done || hipEventQuery(s.done) == hipSuccess) s.touched = false;
+    else (void)hipGetLastError();
     // after everything queued on the caller's stream: uploads the scene depends on, and add-kernels still reading this slot
     hipEvent_t ev = get_event();
     if (!ev) return fail(VP_E_NODEVICE, "hipEventCreate failed");
