@@ -170,7 +170,7 @@ def test_random_scene_bit_exact(vp, oracle, seed):
         buf.free()
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VP_FUZZ_SEQUENCES", "4"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VP_FUZZ_SEQUENCES", "8"))))
 def test_random_call_sequences(vp, oracle, seed):
     """The reference's entry points in random order: render_kernel for consecutive, repeated and far-away frames (the frame
     look-ahead stages consecutive ones in batches), batched vp_render_frames, and between them every setter a host may call --
