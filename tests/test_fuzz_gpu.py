@@ -172,6 +172,17 @@ def test_random_scene_bit_exact(vp, oracle, seed):
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VP_FUZZ_SEQUENCES", "8"))))
 def test_random_call_sequences(vp, oracle, seed):
+    _run_call_sequence(vp, oracle, seed, extra=False)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VP_FUZZ_SEQUENCES_EXTRA", "4"))))
+def test_random_call_sequences_with_invisible_calls(vp, oracle, seed):
+    """The same with the calls of round 3 mixed in that must not change anything: vp_prepare (builds the per-camera tables, pixel
+    lists and sun table ahead of a frame) and the timing read-outs (which synchronise every stream of the context)."""
+    _run_call_sequence(vp, oracle, 500 + seed, extra=True)
+
+
+def _run_call_sequence(vp, oracle, seed, extra):
     """The reference's entry points in random order: render_kernel for consecutive, repeated and far-away frames (the frame
     look-ahead stages consecutive ones in batches), batched vp_render_frames, and between them every setter a host may call --
     Param, camera, estimator, stream, sun, environment, look-ahead depth, accumulator.  Whatever is staged must be dropped when
@@ -253,6 +264,10 @@ def test_random_call_sequences(vp, oracle, seed):
                 st["env_seed"] = int(rng.integers(0, 100)); vp.init_envmap(scenes.synthetic_env(seed=st["env_seed"])); osc = make_oracle(); log.append("env")
             elif u < 0.96:
                 vp.set_lookahead(int(rng.choice([0, 2, 8, 64]))); log.append("lookahead")
+            elif extra and u < 0.975:
+                vp.prepare(P_v); log.append("prepare")
+            elif extra and u < 0.985:
+                vp.render_time_ms(reset=bool(rng.integers(0, 2))); vp.render_class_time_ms(reset=bool(rng.integers(0, 2))); log.append("timers")
             else:
                 cur = 1 - cur; log.append("buffer")
             if step % 23 == 22:
