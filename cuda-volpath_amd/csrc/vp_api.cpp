@@ -128,6 +128,8 @@ struct State
     // the samples of the light class are per-pixel constants when a null collision in empty space leaves a throughput of 1
     // exactly 1 (light_identity_k): decided per (medium, estimator, volume), then miss_fill_k writes them
     bool        use_light_const = true;
+    bool        use_approach = true;          // approach_k ahead of the global-majorant integrator (VP_NO_APPROACH=1: off)
+    unsigned    approach_steps = 1u << 20;    // its step cap per sample (VP_APPROACH_STEPS)
     unsigned*   d_light_flag = nullptr;   // [0] the flag, [1..8] the bytes that occur as maxima in the bound table
     bool        bound_mask_valid = false;
     float       light_key[7] = {};
@@ -248,6 +250,8 @@ int ensure_device()
     if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;
     if (knob("VP_NO_SUN_CLIP", 0, 1, v)) G.use_sun_clip = v == 0;
     if (knob("VP_NO_LIGHT_CONST", 0, 1, v)) G.use_light_const = v == 0;
+    if (knob("VP_NO_APPROACH", 0, 1, v)) G.use_approach = v == 0;
+    if (knob("VP_APPROACH_STEPS", 0, 1 << 30, v)) G.approach_steps = (unsigned)v;
     if (knob("VP_NO_LIGHT", 0, 1, v)) G.use_light = v == 0;
     if (knob("VP_NO_LIGHT_OVERLAP", 0, 1, v)) G.light_overlap = v == 0;
     if (knob("VP_NO_LIGHT_LOCAL", 0, 1, v)) G.use_light_local = v == 0;
@@ -640,10 +644,18 @@ int ensure_sun_clip(const unsigned short** out, float* ds)
 // Are the samples of the light class independent of the draws for this medium (vp_kernels.hip light_identity_k)?  Global-majorant
 // and decomposition estimators with spectral tracking; the bounded estimator's heat channel counts segments, scalar tracking has no
 // light class, float bound tables are not enumerable.
+int ensure_light_identity(const Param* p, bool* out);
 int ensure_light_const(const Param* p, bool* out)
 {
     *out = false;
-    if (!G.use_light_const || G.count || G.trk != VP_TRACK_SPECTRAL || G.est == VP_EST_BOUNDED) return VP_OK;
+    if (!G.use_light_const) return VP_OK;
+    return ensure_light_identity(p, out);
+}
+// the check itself; also what approach_k rests on (a null collision in empty space leaves a throughput of 1 as it is)
+int ensure_light_identity(const Param* p, bool* out)
+{
+    *out = false;
+    if (G.count || G.trk != VP_TRACK_SPECTRAL || G.est == VP_EST_BOUNDED) return VP_OK;
     const bool local = G.est != VP_EST_GLOBAL;
     if (local && !G.quant) return VP_OK;
     const float key[7] = {p->sigma_t.x, p->sigma_t.y, p->sigma_t.z, p->density, p->g, (float)G.est, (float)G.brick};
@@ -805,6 +817,14 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         if (rc) return rc;
         L.thr_n = G.thr_entries;
     }
+    // the camera rays' free flights through certified-empty cells in a kernel of their own (approach_k): global majorant,
+    // counter-based streams, and a medium whose null collisions in empty space leave a throughput of 1 unchanged
+    bool approach = false;
+    if (G.use_approach && G.est == VP_EST_GLOBAL && G.rng != VP_RNG_SAMPLERH && !G.trk && !G.env_mis && !G.count && L.crawl && G.n_general)
+    {
+        rc = ensure_light_identity(p, &approach);
+        if (rc) return rc;
+    }
     const size_t per_frame = sh.per_frame;
     if (0xfffffff0u / per_frame < 1) return fail(VP_E_ARG, "image too large for the 32-bit sample queue");
     L.stage_stride = (unsigned)per_frame;
@@ -938,8 +958,19 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             else
             {
                 ClassTimer ct(0, T.stream);
-                launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, G.trk, (int)blocks, T.stream);
-                le = hipGetLastError();
+                L.approach = 0;
+                if (approach && L.stage && f <= 65535)
+                {
+                    L.approach       = 1;
+                    L.approach_steps = G.approach_steps;
+                    launch_approach(S, L, G.rng, T.stream);
+                    le = hipGetLastError();
+                }
+                if (le == hipSuccess)
+                {
+                    launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, G.trk, (int)blocks, T.stream);
+                    le = hipGetLastError();
+                }
                 // The LDS-table kernel holds 2 x 64 KiB of a CU's LDS with 2 x 512 threads: four waves per SIMD, where the
                 // registers would allow five.  The fifth comes from the SAME kernel without the LDS stage (the brick table read
                 // from global memory), one 256-thread workgroup per CU beside it on the auxiliary stream, drawing from the same
@@ -1428,9 +1459,9 @@ int vp_read_counters(vp_counters* out, int reset)
     }
         if (getenv("VP_DEBUG_COUNTERS"))
         {
-            static const char* names[12] = {"setup", "half-step", "lookup+collision", "segment/ray end", "scatter", "nee", "phase", "background", "write", "refill", "global set-up", "fetch"};
+            static const char* names[14] = {"setup", "half-step", "lookup+collision", "segment/ray end", "scatter", "nee", "phase", "background", "write", "refill", "global set-up", "fetch", "zero fetch (path)", "zero fetch (shadow)"};
             fprintf(stderr, "[vp] block: wave executions, lanes per execution (of 64)\n");
-            for (int b = 0; b < 12; b++)
+            for (int b = 0; b < 14; b++)
                 if (h[16 + 2 * b]) fprintf(stderr, "[vp]   %-18s %14llu  %5.1f\n", names[b], h[16 + 2 * b], (double)h[17 + 2 * b] / (double)h[16 + 2 * b]);
         }
     if (reset) HIPCHK(hipMemset(G.d_counters, 0, sizeof h));

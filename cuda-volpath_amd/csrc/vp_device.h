@@ -110,6 +110,7 @@ struct RngSamplerH
     static constexpr bool kShadowSubstream = false;
     __device__ __forceinline__ void enter_shadow(unsigned) {}
     __device__ __forceinline__ void leave_shadow() {}
+    __device__ __forceinline__ void set_pair(unsigned) {}
 };
 
 // Philox2x32-R (Salmon et al., SC'11; R = 10 or 7), numbered in PAIRS of draws: next_a() computes
@@ -153,6 +154,8 @@ struct RngPhiloxR
     unsigned saved;
     __device__ __forceinline__ void enter_shadow(unsigned id) { saved = pair; pair = 0x80000000u + (id << 20); }
     __device__ __forceinline__ void leave_shadow() { pair = saved; }
+    // take the stream up at pair index n (approach_k has consumed the pairs before it)
+    __device__ __forceinline__ void set_pair(unsigned n) { pair = n; }
 };
 typedef RngPhiloxR<10> RngPhilox;   // VP_RNG_PHILOX
 typedef RngPhiloxR<7>  RngPhilox7;  // VP_RNG_PHILOX7: Random123's smallest Crush-resistant round count

@@ -163,6 +163,9 @@ void render_k(SceneDev S, LaunchDev L)
     // tracked, and where it ends the tracking step itself adds the light and goes on with the new segment.  The sequential
     // sampler.h stream (and the MIS build) keep the reference's order: collision, shadow ray, light, phase function.
     constexpr bool EARLY = RNG::kShadowSubstream && !MIS && !LIGHT;
+    // Global majorant, counter-based streams: a new sample's camera ray may have been walked through its certified-empty stretch by
+    // approach_k already (L.approach): the path is taken up where that walk stopped -- same draws, same sums, made elsewhere.
+    constexpr bool APPR = EST == EST_GLOBAL && RNG::kShadowSubstream && TRK == 0 && !LIGHT && !MIS && !COUNT;
     const ParamDev& P = L.P;
     const f3    sig_t     = f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]};
     const f3    sig_s     = sig_t * f3{P.albedo[0], P.albedo[1], P.albedo[2]};
@@ -208,7 +211,7 @@ void render_k(SceneDev S, LaunchDev L)
     unsigned long long d_iter = 0, d_act = 0, d_outer = 0, d_shadow = 0;  // debug (lane 0 counts wave events)
     unsigned long long t_slow = 0, t_fast = 0, t_mark = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;  // shader cycles
     // COUNT build: how often each code block runs (wave executions) and for how many lanes -- where the lane slots go
-    enum { B_SETUP, B_HALF, B_LOOK, B_EXIT, B_SCATTER, B_NEE, B_HG, B_BG, B_WRITE, B_REFILL, B_GSETUP, B_FETCH, B_NBLK };
+    enum { B_SETUP, B_HALF, B_LOOK, B_EXIT, B_SCATTER, B_NEE, B_HG, B_BG, B_WRITE, B_REFILL, B_GSETUP, B_FETCH, B_ZERO, B_ZERO_SH, B_NBLK };
     unsigned long long bw[B_NBLK] = {}, bl[B_NBLK] = {};
     auto tally = [&](int b, bool on) __attribute__((always_inline)) {
         if (COUNT)
@@ -490,6 +493,7 @@ void render_k(SceneDev S, LaunchDev L)
 #pragma unroll 1
         for (int rep = 0; rep < 4; rep++)
         {
+            bool fresh = false;   // APPR: this lane took a new sample in this round, `dist` holds where approach_k left its camera ray
             // order: a path that ends here is written, its lane refilled and the new segment set up in ONE round
             // ---- ray left the medium: background() kernel.cu:1258-1267 (quirk Q11)
             tally(B_BG, st == EV_BG);
@@ -606,6 +610,13 @@ void render_k(SceneDev S, LaunchDev L)
                                 nsc = 0;
                                 seg = 0;
                                 if (!LIGHT) t_empty = L.crawl ? L.crawl[2 * ((size_t)px + (size_t)py * P.width) + 1].x : 0.0f;
+                                if (APPR && L.approach)
+                                {
+                                    const float4 a = L.stage[item];   // approach_k: distance reached, pairs used
+                                    dist  = a.x;
+                                    rng.set_pair(f2u(a.y));
+                                    fresh = true;
+                                }
                                 if (LOCAL && L.crawl)
                                 {
                                     // the restart crawl in front of the volume, done once per pixel by crawl_table_k: the path starts
@@ -639,7 +650,7 @@ void render_k(SceneDev S, LaunchDev L)
                     if (t_near < 0.0f) t_near = 0.0f;
                     t_far         = tf;
                     t_end         = tf;
-                    dist          = t_near;
+                    dist          = (APPR && fresh) ? dist : t_near;
                     float s       = hyperion_s(nsc - 5);
                     phase_g       = (1.0f - s) * P.g;
                     if (TRK)
@@ -858,6 +869,8 @@ ends_done:
                     }
                     float e   = rng.next_b();
                     if (COUNT) c_den++;
+                    tally(B_ZERO, !LIGHT && !shadow && !(dist < t_empty) && den == 0.0f);
+                    tally(B_ZERO_SH, !LIGHT && shadow && den == 0.0f && !(COUNT && dist >= t_clip));
                     if (TRK)
                     {
                         // scalar delta tracking: kernel.cu:2137-2142 / :745-748 (Tr stops AT its collision, no further draw)
@@ -1377,6 +1390,52 @@ __global__ __launch_bounds__(256) void miss_fill_k(SceneDev S, LaunchDev L, int 
     }
 }
 
+// ---- the camera rays' way to the medium, ahead of the integrator (global-majorant estimator, counter-based streams).
+// A general pixel's camera ray is the same in every frame (quirk Q3) and certified to run through empty cells up to t_empty
+// (empty_table_k): until its free flight passes that distance a path does nothing but draw a pair, take the logarithm of its first
+// word, add and compare -- the collision there is a null collision with density +0 that leaves a throughput of exactly 1 unchanged
+// (light_identity_k has checked that for this medium; the host asks for this kernel only then).  About 500 such steps per sample at
+// the default camera, 44 % of the lane-steps of the integrator's tracking loop on BASELINE config 2 -- where the lanes that make
+// them sit beside lanes that fetch and collide, and wait while those do.  Here a thread per sample makes them and nothing else:
+// slot s of the launch's pixel list in frame f, 64 neighbouring pixels per wave (their walks have about the same length).  It
+// stops BEFORE the first flight that would pass t_empty or leave the box and leaves (distance reached, pairs used) in the sample's
+// staging slot; render_k takes the sample up from there and makes that flight itself (its own test `dist < t_empty` is still in
+// place: any prefix of the walk is a valid hand-over, so the step cap below costs nothing but the steps left over).
+template <class RNG>
+__global__ __launch_bounds__(256) void approach_k(SceneDev S, LaunchDev L)
+{
+    const unsigned slot = blockIdx.x * 256u + threadIdx.x, fl = blockIdx.y;
+    if (slot >= L.nslots) return;
+    const ParamDev& P = L.P;
+    const unsigned pix = L.pixels[slot], px = pix & 0xffffu, py = pix >> 16;
+    if (px >= P.width || py >= P.height) return;   // a partial edge tile: render_k skips the slot as well
+    f3 ro, rd;
+    camera_ray(S, P.width, P.height, px, py, ro, rd);
+    float    t_near, tf, dist = 0.0f;
+    unsigned pairs = 0;
+    if (intersect_box(ro, rd, S, t_near, tf))
+    {
+        // the set-up of render_k's first segment (kernel.cu:1332-1370, depth index 0)
+        if (t_near < 0.0f) t_near = 0.0f;
+        dist                      = t_near;
+        const float t_end         = tf;
+        const float t_empty       = L.crawl[2 * ((size_t)px + (size_t)py * P.width) + 1].x;
+        const float s             = hyperion_s(0 - 5);
+        const float cur_density   = (1.0f - s) * P.density + s * P.density * (1.0f - P.g);
+        const float sigma_t_prime = max3(f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]}) * cur_density;
+        const float inv_sigma     = 1.0f / sigma_t_prime;
+        RNG rng;
+        rng.init(px, py, (unsigned)(L.frame0 + (int)fl), L.key0, L.key1);
+        for (; pairs < L.approach_steps; pairs++)
+        {
+            const float d2 = dist + -logf_(rng.next_a()) * inv_sigma;   // kernel.cu:1419
+            if (!(d2 < t_empty) || d2 >= t_end) break;                   // the integrator's step: a fetch, or the way out
+            dist = d2;
+        }
+    }
+    L.stage[(size_t)fl * L.stage_stride + L.slot_base + slot] = make_float4(dist, u2f(pairs), 0.0f, 0.0f);
+}
+
 // expand a dense volume into per-voxel 2x2x2 neighbourhood cells (clamped at the border)
 __device__ __forceinline__ size_t pack_index(int nx, int ny, int i, int j, int k, int bricks)
 {
@@ -1793,6 +1852,12 @@ void launch_thr_table(const ParamDev& P, float* table, unsigned count, hipStream
 void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimator, hipStream_t st)
 {
     hipLaunchKernelGGL(miss_fill_k, dim3((L.nslots + 255) / 256), dim3(256), 0, st, S, L, local_estimator ? 1 : 0);
+}
+void launch_approach(const SceneDev& S, const LaunchDev& L, int rng, hipStream_t st)
+{
+    const dim3 grid((L.nslots + 255u) / 256u, (unsigned)L.nframes);
+    if (rng == RNG_PHILOX7) hipLaunchKernelGGL(approach_k<RngPhilox7>, grid, dim3(256), 0, st, S, L);
+    else hipLaunchKernelGGL(approach_k<RngPhilox>, grid, dim3(256), 0, st, S, L);
 }
 void launch_pixel_lists(unsigned width, unsigned height, unsigned rank, unsigned world, unsigned ntiles, const unsigned* d_row_start,
                         const float4* table, unsigned* d_block_counts, unsigned* d_totals, unsigned* d_out, hipStream_t st)
