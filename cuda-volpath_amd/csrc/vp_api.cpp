@@ -648,14 +648,14 @@ int ensure_light_identity(const Param* p, bool* out);
 int ensure_light_const(const Param* p, bool* out)
 {
     *out = false;
-    if (!G.use_light_const) return VP_OK;
+    if (!G.use_light_const || G.count) return VP_OK;   // (the counting build walks the light paths: its counters are the estimator's)
     return ensure_light_identity(p, out);
 }
 // the check itself; also what approach_k rests on (a null collision in empty space leaves a throughput of 1 as it is)
 int ensure_light_identity(const Param* p, bool* out)
 {
     *out = false;
-    if (G.count || G.trk != VP_TRACK_SPECTRAL || G.est == VP_EST_BOUNDED) return VP_OK;
+    if (G.trk != VP_TRACK_SPECTRAL || G.est == VP_EST_BOUNDED) return VP_OK;
     const bool local = G.est != VP_EST_GLOBAL;
     if (local && !G.quant) return VP_OK;
     const float key[7] = {p->sigma_t.x, p->sigma_t.y, p->sigma_t.z, p->density, p->g, (float)G.est, (float)G.brick};
@@ -820,7 +820,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     // the camera rays' free flights through certified-empty cells in a kernel of their own (approach_k): global majorant,
     // counter-based streams, and a medium whose null collisions in empty space leave a throughput of 1 unchanged
     bool approach = false;
-    if (G.use_approach && G.est == VP_EST_GLOBAL && G.rng != VP_RNG_SAMPLERH && !G.trk && !G.env_mis && !G.count && L.crawl && G.n_general)
+    if (G.use_approach && G.est == VP_EST_GLOBAL && G.rng != VP_RNG_SAMPLERH && !G.trk && !G.env_mis && L.crawl && G.n_general)
     {
         rc = ensure_light_identity(p, &approach);
         if (rc) return rc;

@@ -165,7 +165,7 @@ void render_k(SceneDev S, LaunchDev L)
     constexpr bool EARLY = RNG::kShadowSubstream && !MIS && !LIGHT;
     // Global majorant, counter-based streams: a new sample's camera ray may have been walked through its certified-empty stretch by
     // approach_k already (L.approach): the path is taken up where that walk stopped -- same draws, same sums, made elsewhere.
-    constexpr bool APPR = EST == EST_GLOBAL && RNG::kShadowSubstream && TRK == 0 && !LIGHT && !MIS && !COUNT;
+    constexpr bool APPR = EST == EST_GLOBAL && RNG::kShadowSubstream && TRK == 0 && !LIGHT && !MIS;
     const ParamDev& P = L.P;
     const f3    sig_t     = f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]};
     const f3    sig_s     = sig_t * f3{P.albedo[0], P.albedo[1], P.albedo[2]};
@@ -1434,6 +1434,7 @@ __global__ __launch_bounds__(256) void approach_k(SceneDev S, LaunchDev L)
         }
     }
     L.stage[(size_t)fl * L.stage_stride + L.slot_base + slot] = make_float4(dist, u2f(pairs), 0.0f, 0.0f);
+    if (L.counters && pairs) atomicAdd(&L.counters[1], (unsigned long long)pairs);   // density lookups the estimator makes on these steps
 }
 
 // expand a dense volume into per-voxel 2x2x2 neighbourhood cells (clamped at the border)
