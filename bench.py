@@ -269,8 +269,10 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
             # as achievable: the frame-filling 512^3 cloud (c4f) sits near it, the Julia workloads far below
             "traffic_GBps": traffic_gbps, "traffic_frac_of_achievable_hbm": (traffic_gbps / HBM_ACHIEVABLE_GBS) if traffic_gbps else None,
             "bounded_by": bounded_by, "valu_issue_frac": valu_frac, "valu_issue_peak_per_s": VALU_ISSUE_PEAK, "lane_util": lane_util,
-            "kernel": "vp::render_k (a launch = the general kernel and, beside it on a second stream, the light kernel of the "
-                      "pixels whose camera ray meets empty cells only; HIP events from the start of the first to the end of the last)",
+            "kernel": "vp::render_k (a launch = the general kernel -- behind vp::approach_k, which walks the camera rays through their "
+                      "certified-empty stretch, where the global-majorant estimator runs on a counter-based stream -- and, where the light "
+                      "pixels are not per-pixel constants, their kernel beside it on a second stream; HIP events from the start of the "
+                      "first to the end of the last; the counters are summed over these kernels)",
             "launch_ms": launch_ms, "launches": launches,
             "loaded_bytes_per_sample": loaded_bps,
             "estimator_bytes_per_sample": estimator_bps,

@@ -2,6 +2,7 @@
    python scripts/block_profile.py c3 [FRAMES]"""
 import os, sys
 os.environ["VP_DEBUG_COUNTERS"] = "1"
+os.environ.setdefault("VP_COUNT_APPROACH", "1")   # tallies of what the timed launch executes (approach_k ahead of the kernel)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cuda-volpath_amd"))
 import volpath as vp

@@ -1,8 +1,9 @@
 """Digest of scripts/profile_bench.sh output: per-launch averages of the render launch.
 
-A render launch is the general kernel render_k<..., LIGHT=false> and, where the workload has light pixels, the light kernel
+A render launch is the general kernel render_k<..., LIGHT=false> -- behind approach_k where the global-majorant estimator runs on a
+counter-based stream -- and, where the workload has light pixels that are not per-pixel constants, the light kernel
 render_k<..., LIGHT=true> beside it on a second stream; bench.py times the pair with HIP events from the start of the first
-to the end of the last.  Counters are summed over both kernels of the timed (non-counting) variant and divided by the number
+to the end of the last.  Counters are summed over these kernels of the timed (non-counting) variant and divided by the number
 of launches (= dispatches of the general kernel)."""
 import collections, csv, glob, json, re, sys
 out = sys.argv[1]
@@ -11,19 +12,22 @@ res = {}
 
 def variant(name):
     name = re.sub(r"RngPhiloxR<\d+>", "RngPhiloxR", name)
+    if "approach_k<" in name:
+        # the camera rays' free flights ahead of the global-majorant general kernel: part of the launch, summed like the light kernel
+        return {"count": False, "light": False, "approach": True}
     m = re.search(r"render_k<([^>]*)>", name)
     if not m:
         return None
     a = [x.strip() for x in m.group(1).split(",")]
-    return {"count": a[3] == "true", "light": len(a) > 8 and a[8] == "true"}
+    return {"count": a[3] == "true", "light": len(a) > 8 and a[8] == "true", "approach": False}
 
 
 ks = glob.glob(f"{out}/kt/**/*kernel_stats.csv", recursive=True)
 if ks:
-    rows = [(r, variant(r["Name"])) for r in csv.DictReader(open(ks[0])) if "render_k" in r["Name"]]
+    rows = [(r, variant(r["Name"])) for r in csv.DictReader(open(ks[0])) if "render_k" in r["Name"] or "approach_k" in r["Name"]]
     rows = [(r, v) for r, v in rows if v and not v["count"]]
-    for key, light in (("kernel_trace", False), ("kernel_trace_light", True)):
-        sel = [r for r, v in rows if v["light"] == light]
+    for key, light, appr in (("kernel_trace", False, False), ("kernel_trace_light", True, False), ("kernel_trace_approach", False, True)):
+        sel = [r for r, v in rows if v["light"] == light and v["approach"] == appr]
         if sel:
             r = max(sel, key=lambda r: float(r["TotalDurationNs"]))
             res[key] = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
@@ -35,7 +39,7 @@ for d in ("fetch", "write", "sq", "tcc"):
             v = variant(r["Kernel_Name"])
             if v and not v["count"]:
                 agg[r["Counter_Name"]] += float(r["Counter_Value"])
-                if not v["light"]:
+                if not v["light"] and not v["approach"]:
                     disp[r["Kernel_Name"]].add(r["Dispatch_Id"])
         # a launch may hold two general kernels (the LDS-table kernel and its helper workgroups without the LDS stage): each is
         # dispatched once per launch, so the launches are the dispatches of any one of them
