@@ -128,6 +128,7 @@ struct State
     // the samples of the light class are per-pixel constants when a null collision in empty space leaves a throughput of 1
     // exactly 1 (light_identity_k): decided per (medium, estimator, volume), then miss_fill_k writes them
     bool        use_light_const = true;
+    bool        use_approach_local = true;    // ... and approach_local_k ahead of the decomposition estimator (VP_NO_APPROACH_LOCAL=1: off)
     bool        use_approach = true;          // approach_k ahead of the global-majorant integrator (VP_NO_APPROACH=1: off)
     unsigned    approach_steps = 1u << 20;    // its step cap per sample (VP_APPROACH_STEPS)
     unsigned*   d_light_flag = nullptr;   // [0] the flag, [1..8] the bytes that occur as maxima in the bound table
@@ -251,6 +252,7 @@ int ensure_device()
     if (knob("VP_NO_SUN_CLIP", 0, 1, v)) G.use_sun_clip = v == 0;
     if (knob("VP_NO_LIGHT_CONST", 0, 1, v)) G.use_light_const = v == 0;
     if (knob("VP_NO_APPROACH", 0, 1, v)) G.use_approach = v == 0;
+    if (knob("VP_NO_APPROACH_LOCAL", 0, 1, v)) G.use_approach_local = v == 0;
     if (knob("VP_APPROACH_STEPS", 0, 1 << 30, v)) G.approach_steps = (unsigned)v;
     if (knob("VP_NO_LIGHT", 0, 1, v)) G.use_light = v == 0;
     if (knob("VP_NO_LIGHT_OVERLAP", 0, 1, v)) G.light_overlap = v == 0;
@@ -820,7 +822,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     // the camera rays' free flights through certified-empty cells in a kernel of their own (approach_k): global majorant,
     // counter-based streams, and a medium whose null collisions in empty space leave a throughput of 1 unchanged
     bool approach = false;
-    if (G.use_approach && G.est == VP_EST_GLOBAL && G.rng != VP_RNG_SAMPLERH && !G.trk && !G.env_mis && L.crawl && G.n_general &&
+    if (G.use_approach && (G.est == VP_EST_GLOBAL || (G.est == VP_EST_DECOMP && G.quant && G.use_approach_local)) && G.rng != VP_RNG_SAMPLERH && !G.trk && !G.env_mis && L.crawl && G.n_general &&
         (!G.count || getenv("VP_COUNT_APPROACH")))   // counting launches: the integrator makes every step itself unless asked (block tallies)
     {
         rc = ensure_light_identity(p, &approach);
@@ -964,8 +966,15 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                 {
                     L.approach       = 1;
                     L.approach_steps = G.approach_steps;
-                    launch_approach(S, L, G.rng, T.stream);
+                    launch_approach(S, L, G.est, G.rng, G.quant, T.stream);
                     le = hipGetLastError();
+                    // the helper workgroups of the LDS-table kernel (auxiliary stream, below) read the staging slots as well: their
+                    // fork point moves behind the walk
+                    if (lds_helper && fork_recorded && le == hipSuccess)
+                    {
+                        fork_recorded = hipEventRecord(G.aux_ev[T.index][0], T.stream) == hipSuccess;
+                        if (!fork_recorded) (void)hipGetLastError();
+                    }
                 }
                 if (le == hipSuccess)
                 {

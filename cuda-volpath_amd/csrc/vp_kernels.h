@@ -98,11 +98,11 @@ struct LaunchDev
                             // 1 = end them where the timed build does (VP_DEBUG_COUNT_CLIPS: block tallies of what the timed kernels execute)
     const float* thr_table; // light kernel of the global-majorant estimator: thr_table[n] = throughput after n null collisions in empty
     unsigned thr_n;         // space (thr_table_k: a function of n alone there), n < thr_n; beyond the table the recurrence is run
-    // Global-majorant estimator, counter-based streams: approach_k has walked the camera ray of every sample of this launch through
-    // its certified-empty stretch already and left (distance reached, draw pairs used) in the sample's staging slot; the
-    // integrator takes a new sample up from there.  0 = start at the box as the reference does.
+    // Counter-based streams: approach_k (global majorant) / approach_local_k (decomposition) has walked the camera ray of every sample
+    // of this launch through its certified-empty stretch already and left (distance reached, draw pairs used) / (segment origin, pairs
+    // used) in the sample's staging slot; the integrator takes a new sample up from there.  0 = start as the reference does.
     unsigned approach;
-    unsigned approach_steps;  // most free-flight steps approach_k walks per sample (the integrator does what is left)
+    unsigned approach_steps;  // most free-flight steps (restart segments) the walk makes per sample (the integrator does what is left)
 };
 
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
@@ -111,7 +111,7 @@ void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool
 void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int blocks, hipStream_t st);
 void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimator, hipStream_t st);
 // the camera rays' free flights through certified-empty cells, one thread per sample of the launch (approach_k); rng: RNG_PHILOX*
-void launch_approach(const SceneDev& S, const LaunchDev& L, int rng, hipStream_t st);
+void launch_approach(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, hipStream_t st);
 // throughput of an unscattered global-majorant path after n null collisions with density +0, n = 0..count-1 (thr_table_k)
 void launch_thr_table(const ParamDev& P, float* table, unsigned count, hipStream_t st);
 // mask[8]: the bytes that occur as a maximum in a uchar bound table; flag[0] (preset to 1) is cleared unless a null collision in

@@ -166,6 +166,8 @@ void render_k(SceneDev S, LaunchDev L)
     // Global majorant, counter-based streams: a new sample's camera ray may have been walked through its certified-empty stretch by
     // approach_k already (L.approach): the path is taken up where that walk stopped -- same draws, same sums, made elsewhere.
     constexpr bool APPR = EST == EST_GLOBAL && RNG::kShadowSubstream && TRK == 0 && !LIGHT && !MIS;
+    // decomposition estimator: the same for the restart segments that end before the certified-empty distance (approach_local_k)
+    constexpr bool APPR_L = EST == EST_DECOMP && RNG::kShadowSubstream && TRK == 0 && !LIGHT && !MIS;
     const ParamDev& P = L.P;
     const f3    sig_t     = f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]};
     const f3    sig_s     = sig_t * f3{P.albedo[0], P.albedo[1], P.albedo[2]};
@@ -627,6 +629,18 @@ void render_k(SceneDev S, LaunchDev L)
                                     rng.skip(k >> 16);
                                     if (EST == EST_BOUNDED) seg = (int)(k & 0xffffu);
                                     if (COUNT) c_bnd += k & 0xffffu;
+                                    if (APPR_L && L.approach)
+                                    {
+                                        // approach_local_k walked on from there: origin of the first segment it did not finish, pairs used
+                                        // so far.  The certificate is measured from the segment origin: less the distance walked (the
+                                        // projection on the ray, a margin of 1e-4 against its rounding: a shorter certificate renders the
+                                        // same bits, it only fetches a zero it could have skipped)
+                                        const float4 a  = L.stage[item];
+                                        const f3     ra = f3{a.x, a.y, a.z};
+                                        t_empty = t_empty - dot(ra - ro, rd) - 1e-4f;
+                                        ro      = ra;
+                                        rng.set_pair(f2u(a.w));
+                                    }
                                 }
                                 st  = ST_SETUP;
                                 segment_medium();
@@ -1437,6 +1451,77 @@ __global__ __launch_bounds__(256) void approach_k(SceneDev S, LaunchDev L)
     if (L.counters && pairs) atomicAdd(&L.counters[1], (unsigned long long)pairs);   // density lookups the estimator makes on these steps
 }
 
+// The same for the decomposition estimator (uchar bound table): behind the crawl in front of the box (crawl_table_k) the camera ray
+// walks restart segments of 0.05 through bricks whose cells it is certified not to meet non-empty (t_empty): a bound fetch, and free
+// flights with the brick's majorant whose null collisions change nothing (light_identity_k: for every majorant in the table), until
+// the flight leaves the segment.  A thread per sample walks every segment that ENDS before the certified distance -- no fetch can
+// fall into it -- and hands over at the origin of the first one that does not (or whose brick has a positive minimum: the control
+// distance is the integrator's business): (origin, pairs used) in the sample's staging slot.  A segment it started and could not
+// finish is simply made again by render_k, from its start, with the same pairs.
+template <class RNG, bool QUANT>
+__global__ __launch_bounds__(256) void approach_local_k(SceneDev S, LaunchDev L)
+{
+    const unsigned slot = blockIdx.x * 256u + threadIdx.x, fl = blockIdx.y;
+    if (slot >= L.nslots) return;
+    const ParamDev& P = L.P;
+    const unsigned pix = L.pixels[slot], px = pix & 0xffffu, py = pix >> 16;
+    if (px >= P.width || py >= P.height) return;
+    f3 ro, rd;
+    camera_ray(S, P.width, P.height, px, py, ro, rd);
+    const f3     inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
+    const size_t idx    = (size_t)px + (size_t)py * P.width;
+    const float4 c      = L.crawl[2 * idx];
+    float        t_empty = L.crawl[2 * idx + 1].x;
+    ro                  = f3{c.x, c.y, c.z};
+    unsigned pairs      = f2u(c.w) >> 16;   // the crawl's draws
+    // segment_medium() of render_k for an unscattered path
+    const float s           = hyperion_s(0 - 5);
+    const float reduction   = (1.0f - s) + s * (1.0f - P.g);
+    const float cur_density = reduction * P.density;
+    const float max_sig     = max3(f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]});
+    RNG rng;
+    rng.init(px, py, (unsigned)(L.frame0 + (int)fl), L.key0, L.key1);
+    unsigned long long n_steps = 0, n_segs = 0;
+    for (unsigned n = 0; n < L.approach_steps; n++)
+    {
+        // segment_setup() of render_k (intersectSuperVolume kernel.cu:1626-1661)
+        float t_near, tf;
+        const bool hit = intersect_box_inv(ro, inv_rd, S, t_near, tf);
+        t_near         = fmaxf(t_near, 0.0f);
+        const float t_far = fminf(tf, 0.05f);
+        float bx, by;
+        sample_bound<QUANT>(S, ro + rd * t_near, bx, by);
+        if (!hit || by > 0.0f) break;
+        const float d_max         = fmaxf(0.0001f, bx);
+        const float sigma_t_prime = max_sig * cur_density * d_max;
+        const float inv_sigma     = 1.0f / sigma_t_prime;
+        float    dist = t_near;
+        unsigned p    = pairs;
+        bool     through = false;
+        for (;;)
+        {
+            rng.set_pair(p);
+            const float d2 = dist + -logf_(rng.next_a()) * inv_sigma;   // kernel.cu:2085
+            p++;
+            if (d2 >= t_far) { through = true; break; }                   // t_end = min(1e20, t_far): `through`, kernel.cu:2145
+            if (!(d2 < t_empty) || p - pairs > 60000u) break;             // a fetch: render_k's
+            dist = d2;
+        }
+        if (!through) break;
+        n_steps += p - pairs - 1u;
+        n_segs++;
+        pairs   = p;
+        ro      = ro + rd * t_far;   // tracking restart kernel.cu:2151-2155
+        t_empty -= t_far;
+    }
+    L.stage[(size_t)fl * L.stage_stride + L.slot_base + slot] = make_float4(ro.x, ro.y, ro.z, u2f(pairs));
+    if (L.counters)
+    {
+        if (n_steps) atomicAdd(&L.counters[1], n_steps);   // density lookups and bound lookups the estimator makes on this stretch
+        if (n_segs) atomicAdd(&L.counters[2], n_segs);
+    }
+}
+
 // expand a dense volume into per-voxel 2x2x2 neighbourhood cells (clamped at the border)
 __device__ __forceinline__ size_t pack_index(int nx, int ny, int i, int j, int k, int bricks)
 {
@@ -1854,11 +1939,24 @@ void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimato
 {
     hipLaunchKernelGGL(miss_fill_k, dim3((L.nslots + 255) / 256), dim3(256), 0, st, S, L, local_estimator ? 1 : 0);
 }
-void launch_approach(const SceneDev& S, const LaunchDev& L, int rng, hipStream_t st)
+void launch_approach(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, hipStream_t st)
 {
     const dim3 grid((L.nslots + 255u) / 256u, (unsigned)L.nframes);
-    if (rng == RNG_PHILOX7) hipLaunchKernelGGL(approach_k<RngPhilox7>, grid, dim3(256), 0, st, S, L);
-    else hipLaunchKernelGGL(approach_k<RngPhilox>, grid, dim3(256), 0, st, S, L);
+    if (est == EST_GLOBAL)
+    {
+        if (rng == RNG_PHILOX7) hipLaunchKernelGGL(approach_k<RngPhilox7>, grid, dim3(256), 0, st, S, L);
+        else hipLaunchKernelGGL(approach_k<RngPhilox>, grid, dim3(256), 0, st, S, L);
+    }
+    else if (quant)
+    {
+        if (rng == RNG_PHILOX7) hipLaunchKernelGGL((approach_local_k<RngPhilox7, true>), grid, dim3(256), 0, st, S, L);
+        else hipLaunchKernelGGL((approach_local_k<RngPhilox, true>), grid, dim3(256), 0, st, S, L);
+    }
+    else
+    {
+        if (rng == RNG_PHILOX7) hipLaunchKernelGGL((approach_local_k<RngPhilox7, false>), grid, dim3(256), 0, st, S, L);
+        else hipLaunchKernelGGL((approach_local_k<RngPhilox, false>), grid, dim3(256), 0, st, S, L);
+    }
 }
 void launch_pixel_lists(unsigned width, unsigned height, unsigned rank, unsigned world, unsigned ntiles, const unsigned* d_row_start,
                         const float4* table, unsigned* d_block_counts, unsigned* d_totals, unsigned* d_out, hipStream_t st)
