@@ -561,7 +561,7 @@ def test_cloud_workload_is_bit_exact_at_reduced_size(vp, oracle, tmp_path):
 def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
     """"results never depend on the knobs".  A context reads the VP_* environment when it is created:
     contexts created under different settings -- tables, sun table, constant light class, light kernel, helper workgroups, LDS
-    stage, cell order, chunk shape, wait / set-up / end policies, one staged frame per launch -- render the same bits as the
+    stage, cell order, chunk shape, wait / set-up / end policies, one staged frame per launch, the approach kernels -- render the same bits as the
     default context, which in turn equals the oracle."""
     W, H = 96, 64
     grid = oracle.julia(64)
@@ -603,6 +603,9 @@ def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
         dict(VP_NO_LDS_HELPER="1"), dict(VP_NO_LDS_BOUNDS="1"), dict(VP_CELL_BRICKS="1"), dict(VP_CHUNK_FRAMES_LOG2="1"),
         dict(VP_WAIT_LANES="5", VP_WAIT_ITERS="4", VP_SETUP_LANES="1", VP_END_LANES="1"), dict(VP_END_LANES="40", VP_SETUP_LANES="33"),
         dict(VP_STAGE_MB="1", VP_BLOCKS_PER_CU="2"), dict(VP_NO_LIGHT_OVERLAP="1", VP_NO_LIGHT_CONST="1"),
+        # the camera rays' walk ahead of the integrator (approach_k / approach_local_k): off, cut short after a few steps / segments
+        dict(VP_NO_APPROACH="1"), dict(VP_NO_APPROACH_LOCAL="1"), dict(VP_APPROACH_STEPS="3"), dict(VP_APPROACH_STEPS="0"),
+        dict(VP_APPROACH_STEPS="40", VP_NO_LDS_HELPER="1"),
     ]
     for env_set in settings:
         saved = {k: os.environ.get(k) for k in env_set}

@@ -75,6 +75,37 @@ def test_julia32_frames_bit_exact(vp, oracle, est, rng_mode):
     buf.free()
 
 
+@pytest.mark.parametrize("est,brick", [(0, 1), (1, 1), (1, 8)])
+@pytest.mark.parametrize("rng_mode", [1, 2])
+def test_approach_kernels_walk_the_estimators_steps(vp, oracle, est, brick, rng_mode, monkeypatch):
+    """approach_k / approach_local_k walk the camera rays through their certified-empty stretch ahead of the integrator (counter-based
+    streams, staged launches).  A counting launch makes those steps in the integrator itself unless VP_COUNT_APPROACH is set; with
+    it the walk's steps and segments are tallied by the approach kernels: image and work counters == oracle either way, and
+    the integrator is left with fewer density lookups of its own than the estimator makes."""
+    grid = oracle.julia(64)
+    osc, oP, vP = _setup(vp, oracle, grid, est, rng_mode, brick=brick, key=(31, 7))
+    if est == 1:
+        osc.precompute_opacity()
+        vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+    frames = list(range(7, 13))
+    ref, cnt = _oracle_frames(osc, oP, frames)
+    buf = vp.DeviceBuffer(W, H)
+    for walk in (False, True):
+        if walk:
+            monkeypatch.setenv("VP_COUNT_APPROACH", "1")
+        buf.reset()
+        vp.enable_counters(True)
+        vp.read_counters(reset=True)
+        vp.render_frames(buf.ptr, frames[0], len(frames), vP)
+        got = buf.download()
+        c = vp.read_counters()
+        vp.enable_counters(False)
+        assert np.array_equal(got, ref), (walk, float(np.abs(got - ref).max()))
+        for k in ("samples", "density_lookups", "bound_lookups", "opacity_lookups", "env_lookups", "scatters"):
+            assert c[k] == cnt[k], (walk, k, c[k], cnt[k])
+    buf.free()
+
+
 @pytest.mark.parametrize("brick", [1, 8])
 def test_julia64_chromatic_bricks(vp, oracle, brick):
     grid = oracle.julia(64)
