@@ -111,6 +111,9 @@ struct RngSamplerH
     __device__ __forceinline__ void enter_shadow(unsigned) {}
     __device__ __forceinline__ void leave_shadow() {}
     __device__ __forceinline__ void set_pair(unsigned) {}
+    // where the stream stands, in two words (approach_k hands a path over to render_k)
+    __device__ __forceinline__ void save(unsigned& a, unsigned& b) const { a = sx; b = sy; }
+    __device__ __forceinline__ void load(unsigned a, unsigned b) { sx = a; sy = b; }
 };
 
 // Philox2x32-R (Salmon et al., SC'11; R = 10 or 7), numbered in PAIRS of draws: next_a() computes
@@ -156,6 +159,8 @@ struct RngPhiloxR
     __device__ __forceinline__ void leave_shadow() { pair = saved; }
     // take the stream up at pair index n (approach_k has consumed the pairs before it)
     __device__ __forceinline__ void set_pair(unsigned n) { pair = n; }
+    __device__ __forceinline__ void save(unsigned& a, unsigned& b) const { a = pair; b = 0u; }
+    __device__ __forceinline__ void load(unsigned a, unsigned) { pair = a; }
 };
 typedef RngPhiloxR<10> RngPhilox;   // VP_RNG_PHILOX
 typedef RngPhiloxR<7>  RngPhilox7;  // VP_RNG_PHILOX7: Random123's smallest Crush-resistant round count

@@ -165,7 +165,7 @@ void render_k(SceneDev S, LaunchDev L)
     constexpr bool EARLY = RNG::kShadowSubstream && !MIS && !LIGHT;
     // Global majorant, counter-based streams: a new sample's camera ray may have been walked through its certified-empty stretch by
     // approach_k already (L.approach): the path is taken up where that walk stopped -- same draws, same sums, made elsewhere.
-    constexpr bool APPR = EST == EST_GLOBAL && RNG::kShadowSubstream && TRK == 0 && !LIGHT && !MIS;
+    constexpr bool APPR = EST == EST_GLOBAL && TRK == 0 && !LIGHT && !MIS;   // (any stream: the hand-over carries its state)
     // decomposition estimator: the same for the restart segments that end before the certified-empty distance (approach_local_k)
     constexpr bool APPR_L = EST == EST_DECOMP && RNG::kShadowSubstream && TRK == 0 && !LIGHT && !MIS;
     const ParamDev& P = L.P;
@@ -614,9 +614,9 @@ void render_k(SceneDev S, LaunchDev L)
                                 if (!LIGHT) t_empty = L.crawl ? L.crawl[2 * ((size_t)px + (size_t)py * P.width) + 1].x : 0.0f;
                                 if (APPR && L.approach)
                                 {
-                                    const float4 a = L.stage[item];   // approach_k: distance reached, pairs used
+                                    const float4 a = L.stage[item];   // approach_k: distance reached, where the stream stands
                                     dist  = a.x;
-                                    rng.set_pair(f2u(a.y));
+                                    rng.load(f2u(a.y), f2u(a.z));
                                     fresh = true;
                                 }
                                 if (LOCAL && L.crawl)
@@ -1426,7 +1426,8 @@ __global__ __launch_bounds__(256) void approach_k(SceneDev S, LaunchDev L)
     f3 ro, rd;
     camera_ray(S, P.width, P.height, px, py, ro, rd);
     float    t_near, tf, dist = 0.0f;
-    unsigned pairs = 0;
+    unsigned pairs = 0, sa = 0, sb = 0;   // steps made; the stream's state before the step in hand
+    RNG      rng;
     if (intersect_box(ro, rd, S, t_near, tf))
     {
         // the set-up of render_k's first segment (kernel.cu:1332-1370, depth index 0)
@@ -1438,16 +1439,18 @@ __global__ __launch_bounds__(256) void approach_k(SceneDev S, LaunchDev L)
         const float cur_density   = (1.0f - s) * P.density + s * P.density * (1.0f - P.g);
         const float sigma_t_prime = max3(f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]}) * cur_density;
         const float inv_sigma     = 1.0f / sigma_t_prime;
-        RNG rng;
         rng.init(px, py, (unsigned)(L.frame0 + (int)fl), L.key0, L.key1);
+        rng.save(sa, sb);
         for (; pairs < L.approach_steps; pairs++)
         {
             const float d2 = dist + -logf_(rng.next_a()) * inv_sigma;   // kernel.cu:1419
             if (!(d2 < t_empty) || d2 >= t_end) break;                   // the integrator's step: a fetch, or the way out
             dist = d2;
+            (void)rng.next_b();   // the collision test's variate: `real` is false whatever it is; a sequential stream moves past it
+            rng.save(sa, sb);
         }
     }
-    L.stage[(size_t)fl * L.stage_stride + L.slot_base + slot] = make_float4(dist, u2f(pairs), 0.0f, 0.0f);
+    L.stage[(size_t)fl * L.stage_stride + L.slot_base + slot] = make_float4(dist, u2f(sa), u2f(sb), 0.0f);
     if (L.counters && pairs) atomicAdd(&L.counters[1], (unsigned long long)pairs);   // density lookups the estimator makes on these steps
 }
 
@@ -1945,7 +1948,8 @@ void launch_approach(const SceneDev& S, const LaunchDev& L, int est, int rng, bo
     if (est == EST_GLOBAL)
     {
         if (rng == RNG_PHILOX7) hipLaunchKernelGGL(approach_k<RngPhilox7>, grid, dim3(256), 0, st, S, L);
-        else hipLaunchKernelGGL(approach_k<RngPhilox>, grid, dim3(256), 0, st, S, L);
+        else if (rng == RNG_PHILOX) hipLaunchKernelGGL(approach_k<RngPhilox>, grid, dim3(256), 0, st, S, L);
+        else hipLaunchKernelGGL(approach_k<RngSamplerH>, grid, dim3(256), 0, st, S, L);
     }
     else if (quant)
     {
