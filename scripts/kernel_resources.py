@@ -16,7 +16,7 @@ for l in out.splitlines():
     elif cur is not None:
         cur[k] = v
 for r in rows:
-    if "render_k" not in r["name"]:
+    if "render_k" not in r["name"] and "approach" not in r["name"]:
         continue
     n = subprocess.run(["c++filt", r["name"]], capture_output=True, text=True).stdout.strip()
     n = re.sub(r"\(SceneDev, LaunchDev\)|void ", "", n.replace("vp::", ""))

@@ -12,7 +12,7 @@ res = {}
 
 def variant(name):
     name = re.sub(r"RngPhiloxR<\d+>", "RngPhiloxR", name)
-    if "approach_k<" in name:
+    if "approach_k<" in name or "approach_local_k<" in name:
         # the camera rays' free flights ahead of the global-majorant general kernel: part of the launch, summed like the light kernel
         return {"count": False, "light": False, "approach": True}
     m = re.search(r"render_k<([^>]*)>", name)
@@ -24,7 +24,7 @@ def variant(name):
 
 ks = glob.glob(f"{out}/kt/**/*kernel_stats.csv", recursive=True)
 if ks:
-    rows = [(r, variant(r["Name"])) for r in csv.DictReader(open(ks[0])) if "render_k" in r["Name"] or "approach_k" in r["Name"]]
+    rows = [(r, variant(r["Name"])) for r in csv.DictReader(open(ks[0])) if "render_k" in r["Name"] or "approach_k" in r["Name"] or "approach_local_k" in r["Name"]]
     rows = [(r, v) for r, v in rows if v and not v["count"]]
     for key, light, appr in (("kernel_trace", False, False), ("kernel_trace_light", True, False), ("kernel_trace_approach", False, True)):
         sel = [r for r, v in rows if v["light"] == light and v["approach"] == appr]
