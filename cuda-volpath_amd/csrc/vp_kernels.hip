@@ -12,6 +12,9 @@
 // distance up to which the ray meets only empty cells, the pixel's class -- and pixels whose ray never meets a non-empty
 // cell are per-pixel constants where a null collision in empty space leaves the throughput at exactly 1 (light_identity_k,
 // miss_fill_k), else they run the LIGHT specialisation of the kernel beside the general one.
+// approach_k / approach_local_k: in staged launches the remaining pixels' camera rays are walked through their certified-empty
+// stretch -- draw, logarithm, add, compare -- by a thread per sample ahead of render_k, which takes each path up from its
+// staging slot: work sorted by kind across the chip instead of lanes waiting beside lanes that fetch.
 // Restates
 //   __d_render_bounded_decomp  kernel.cu:1958-2318  (EST_DECOMP, the reference's live kernel)
 //   __d_render                 kernel.cu:1285-1591  (EST_GLOBAL, BASELINE config 2)
