@@ -819,13 +819,16 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         if (rc) return rc;
         L.thr_n = G.thr_entries;
     }
-    // the camera rays' free flights through certified-empty cells in a kernel of their own (approach_k): global majorant,
-    // counter-based streams, and a medium whose null collisions in empty space leave a throughput of 1 unchanged
+    // the camera rays' free flights through certified-empty cells in kernels of their own (approach_k: global majorant, any stream;
+    // approach_local_k: decomposition estimator, counter-based streams), where a null collision in empty space leaves a
+    // throughput of 1 unchanged
     bool approach = false;
-    if (G.use_approach && (G.est == VP_EST_GLOBAL || (G.est == VP_EST_DECOMP && G.quant && G.use_approach_local && G.rng != VP_RNG_SAMPLERH)) && !G.trk && !G.env_mis && L.crawl && G.n_general &&
+    if (G.use_approach && (G.est == VP_EST_GLOBAL || (G.est == VP_EST_DECOMP && G.use_approach_local && G.rng != VP_RNG_SAMPLERH)) && !G.trk && !G.env_mis && L.crawl && G.n_general &&
         (!G.count || getenv("VP_COUNT_APPROACH")))   // counting launches: the integrator makes every step itself unless asked (block tallies)
     {
-        rc = ensure_light_identity(p, &approach);
+        // global majorant: one majorant for the whole walk, checked here; decomposition: approach_local_k checks each segment's own
+        if (G.est == VP_EST_GLOBAL) rc = ensure_light_identity(p, &approach);
+        else approach = true;
         if (rc) return rc;
     }
     const size_t per_frame = sh.per_frame;

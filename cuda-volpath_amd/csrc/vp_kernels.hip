@@ -1459,8 +1459,7 @@ __global__ __launch_bounds__(256) void approach_k(SceneDev S, LaunchDev L)
 
 // The same for the decomposition estimator (uchar bound table): behind the crawl in front of the box (crawl_table_k) the camera ray
 // walks restart segments of 0.05 through bricks whose cells it is certified not to meet non-empty (t_empty): a bound fetch, and free
-// flights with the brick's majorant whose null collisions change nothing (light_identity_k: for every majorant in the table), until
-// the flight leaves the segment.  A thread per sample walks every segment that ENDS before the certified distance -- no fetch can
+// flights with the brick's majorant whose null collisions change nothing (checked per segment), until the flight leaves the segment.  A thread per sample walks every segment that ENDS before the certified distance -- no fetch can
 // fall into it -- and hands over at the origin of the first one that does not (or whose brick has a positive minimum: the control
 // distance is the integrator's business): (origin, pairs used) in the sample's staging slot.  A segment it started and could not
 // finish is simply made again by render_k, from its start, with the same pairs.
@@ -1501,6 +1500,9 @@ __global__ __launch_bounds__(256) void approach_local_k(SceneDev S, LaunchDev L)
         const float d_max         = fmaxf(0.0001f, bx);
         const float sigma_t_prime = max_sig * cur_density * d_max;
         const float inv_sigma     = 1.0f / sigma_t_prime;
+        // a null collision in empty space must leave the throughput of 1 as it is for THIS majorant (most do; the constant light class
+        // asks it of every majorant in the table, light_identity_k): where it does not, the integrator goes on from here
+        if (!(null_collision_in_empty_space(1.0f, sigma_t_prime, inv_sigma) == 1.0f)) break;
         float    dist = t_near;
         unsigned p    = pairs;
         bool     through = false;
