@@ -240,9 +240,12 @@ void render_k(SceneDev S, LaunchDev L)
         if (COUNT && lane == 0) d_outer++;
         // =========================================================== slow path: events
         // The event section reads its uniforms (camera, sun, environment, queue and image descriptors: ~70 scalars that the
-        // tracking loop never touches) from the kernel-argument segment afresh in every visit -- a few scalar loads that hit
-        // the scalar cache -- instead of holding them in SGPRs across the tracking loop, whose own scalars then fit without
-        // spilling into vector lanes.  The empty asm keeps the compiler from hoisting those loads back out of the loop.
+        // tracking loop never touches) from the kernel-argument segment afresh in every visit instead of holding them in SGPRs
+        // across the tracking loop, whose own scalars then fit without spilling into vector lanes.  The empty asm keeps the
+        // compiler from hoisting those loads back out of the loop; it also makes the pointer divergent for it, so the reads are
+        // per-lane flat loads of the fields a visit's branches need (one L1-resident line for every wave of the CU), not scalar
+        // loads -- which, tried, load the whole structs and spill 35-49 SGPRs: -20...-45 % (profiles/experiments/
+        // r03_scalar_kernarg_reload.txt).
         {
         const char* kargs_ = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kargs_));
