@@ -128,6 +128,8 @@ struct State
     // the samples of the light class are per-pixel constants when a null collision in empty space leaves a throughput of 1
     // exactly 1 (light_identity_k): decided per (medium, estimator, volume), then miss_fill_k writes them
     bool        use_light_const = true;
+    unsigned*   d_appr_aux[3] = {nullptr, nullptr, nullptr};   // per render target (caller's stream, two look-ahead slots): LaunchDev::approach_aux
+    size_t      appr_aux_bytes[3] = {0, 0, 0};
     bool        use_approach_local = true;    // ... and approach_local_k ahead of the decomposition estimator (VP_NO_APPROACH_LOCAL=1: off)
     bool        use_approach = true;          // approach_k ahead of the global-majorant integrator (VP_NO_APPROACH=1: off)
     unsigned    approach_steps = 1u << 20;    // its step cap per sample (VP_APPROACH_STEPS)
@@ -823,7 +825,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     // approach_local_k: decomposition estimator, counter-based streams), where a null collision in empty space leaves a
     // throughput of 1 unchanged
     bool approach = false;
-    if (G.use_approach && (G.est == VP_EST_GLOBAL || (G.est == VP_EST_DECOMP && G.use_approach_local && G.rng != VP_RNG_SAMPLERH)) && !G.trk && !G.env_mis && L.crawl && G.n_general &&
+    if (G.use_approach && (G.est == VP_EST_GLOBAL || (G.est == VP_EST_DECOMP && G.use_approach_local)) && !G.trk && !G.env_mis && L.crawl && G.n_general &&
         (!G.count || getenv("VP_COUNT_APPROACH")))   // counting launches: the integrator makes every step itself unless asked (block tallies)
     {
         // global majorant: one majorant for the whole walk, checked here; decomposition: approach_local_k checks each segment's own
@@ -965,7 +967,23 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             {
                 ClassTimer ct(0, T.stream);
                 L.approach = 0;
-                if (approach && L.stage && f <= 65535)
+                bool aux_ok = true;
+                if (approach && L.stage && G.est == VP_EST_DECOMP && G.rng == VP_RNG_SAMPLERH)
+                {
+                    // sampler.h's state is two words and the staging slot holds the segment origin and one: the other goes beside it
+                    const int    ti    = T.index;
+                    const size_t need4 = per_frame * (size_t)f * sizeof(unsigned);
+                    if (need4 > G.appr_aux_bytes[ti])
+                    {
+                        HIPCHK(hipStreamSynchronize(T.stream));
+                        if (G.d_appr_aux[ti]) HIPCHK(hipFree(G.d_appr_aux[ti]));
+                        G.d_appr_aux[ti] = nullptr; G.appr_aux_bytes[ti] = 0;
+                        if (hipMalloc((void**)&G.d_appr_aux[ti], need4) != hipSuccess) { (void)hipGetLastError(); G.d_appr_aux[ti] = nullptr; aux_ok = false; }
+                        else G.appr_aux_bytes[ti] = need4;
+                    }
+                    L.approach_aux = G.d_appr_aux[ti];
+                }
+                if (approach && aux_ok && L.stage && f <= 65535)
                 {
                     L.approach       = 1;
                     L.approach_steps = G.approach_steps;
@@ -1346,6 +1364,7 @@ int vp_ctx_destroy(vp_ctx* ctx)
         for (int i = 0; i < 3; i++)
         {
             if (D.aux_stream[i]) { (void)hipStreamSynchronize(D.aux_stream[i]); (void)hipStreamDestroy(D.aux_stream[i]); }
+            if (D.d_appr_aux[i]) (void)hipFree(D.d_appr_aux[i]);
             for (int q = 0; q < 2; q++) if (D.aux_ev[i][q]) (void)hipEventDestroy(D.aux_ev[i][q]);
         }
         if (D.ctrl_stream) (void)hipStreamDestroy(D.ctrl_stream);

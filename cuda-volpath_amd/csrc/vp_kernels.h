@@ -101,6 +101,7 @@ struct LaunchDev
     // Counter-based streams: approach_k (global majorant) / approach_local_k (decomposition) has walked the camera ray of every sample
     // of this launch through its certified-empty stretch already and left (distance reached, draw pairs used) / (segment origin, pairs
     // used) in the sample's staging slot; the integrator takes a new sample up from there.  0 = start as the reference does.
+    unsigned* approach_aux;   // sampler.h + decomposition: the second word of the stream's state per staging slot (the slot holds four)
     unsigned approach;
     unsigned approach_steps;  // most free-flight steps (restart segments) the walk makes per sample (the integrator does what is left)
 };

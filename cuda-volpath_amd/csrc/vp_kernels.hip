@@ -170,7 +170,7 @@ void render_k(SceneDev S, LaunchDev L)
     // approach_k already (L.approach): the path is taken up where that walk stopped -- same draws, same sums, made elsewhere.
     constexpr bool APPR = EST == EST_GLOBAL && TRK == 0 && !LIGHT && !MIS;   // (any stream: the hand-over carries its state)
     // decomposition estimator: the same for the restart segments that end before the certified-empty distance (approach_local_k)
-    constexpr bool APPR_L = EST == EST_DECOMP && RNG::kShadowSubstream && TRK == 0 && !LIGHT && !MIS;
+    constexpr bool APPR_L = EST == EST_DECOMP && TRK == 0 && !LIGHT && !MIS;
     const ParamDev& P = L.P;
     const f3    sig_t     = f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]};
     const f3    sig_s     = sig_t * f3{P.albedo[0], P.albedo[1], P.albedo[2]};
@@ -632,7 +632,7 @@ void render_k(SceneDev S, LaunchDev L)
                                     float4   c = L.crawl[2 * ((size_t)px + (size_t)py * P.width)];
                                     unsigned k = f2u(c.w);
                                     ro = f3{c.x, c.y, c.z};
-                                    rng.skip(k >> 16);
+                                    if (!(APPR_L && L.approach)) rng.skip(k >> 16);   // (else the hand-over below carries the stream's state)
                                     if (EST == EST_BOUNDED) seg = (int)(k & 0xffffu);
                                     if (COUNT) c_bnd += k & 0xffffu;
                                     if (APPR_L && L.approach)
@@ -645,7 +645,8 @@ void render_k(SceneDev S, LaunchDev L)
                                         const f3     ra = f3{a.x, a.y, a.z};
                                         t_empty = t_empty - dot(ra - ro, rd) - 1e-4f;
                                         ro      = ra;
-                                        rng.set_pair(f2u(a.w));
+                                        // where the stream stands: the pair index, or sampler.h's two words (the second beside the slot)
+                                        rng.load(f2u(a.w), RNG::kShadowSubstream ? 0u : L.approach_aux[item]);
                                     }
                                 }
                                 st  = ST_SETUP;
@@ -1481,7 +1482,6 @@ __global__ __launch_bounds__(256) void approach_local_k(SceneDev S, LaunchDev L)
     const float4 c      = L.crawl[2 * idx];
     float        t_empty = L.crawl[2 * idx + 1].x;
     ro                  = f3{c.x, c.y, c.z};
-    unsigned pairs      = f2u(c.w) >> 16;   // the crawl's draws
     // segment_medium() of render_k for an unscattered path
     const float s           = hyperion_s(0 - 5);
     const float reduction   = (1.0f - s) + s * (1.0f - P.g);
@@ -1489,6 +1489,9 @@ __global__ __launch_bounds__(256) void approach_local_k(SceneDev S, LaunchDev L)
     const float max_sig     = max3(f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]});
     RNG rng;
     rng.init(px, py, (unsigned)(L.frame0 + (int)fl), L.key0, L.key1);
+    rng.skip(f2u(c.w) >> 16);   // the crawl's draws
+    unsigned sa, sb;            // where the stream stands at the origin of the segment in hand
+    rng.save(sa, sb);
     unsigned long long n_steps = 0, n_segs = 0;
     for (unsigned n = 0; n < L.approach_steps; n++)
     {
@@ -1507,25 +1510,27 @@ __global__ __launch_bounds__(256) void approach_local_k(SceneDev S, LaunchDev L)
         // asks it of every majorant in the table, light_identity_k): where it does not, the integrator goes on from here
         if (!(null_collision_in_empty_space(1.0f, sigma_t_prime, inv_sigma) == 1.0f)) break;
         float    dist = t_near;
-        unsigned p    = pairs;
+        unsigned steps = 0;
         bool     through = false;
         for (;;)
         {
-            rng.set_pair(p);
             const float d2 = dist + -logf_(rng.next_a()) * inv_sigma;   // kernel.cu:2085
-            p++;
             if (d2 >= t_far) { through = true; break; }                   // t_end = min(1e20, t_far): `through`, kernel.cu:2145
-            if (!(d2 < t_empty) || p - pairs > 60000u) break;             // a fetch: render_k's
+            if (!(d2 < t_empty) || steps > 60000u) break;                 // a fetch: render_k's
             dist = d2;
+            (void)rng.next_b();   // the collision test's variate (`real` is false whatever it is): a sequential stream moves past it
+            steps++;
         }
-        if (!through) break;
-        n_steps += p - pairs - 1u;
+        if (!through) break;      // (the stream's state at the origin of this segment is what is handed over)
+        rng.save(sa, sb);
+        n_steps += steps;
         n_segs++;
-        pairs   = p;
         ro      = ro + rd * t_far;   // tracking restart kernel.cu:2151-2155
         t_empty -= t_far;
     }
-    L.stage[(size_t)fl * L.stage_stride + L.slot_base + slot] = make_float4(ro.x, ro.y, ro.z, u2f(pairs));
+    const size_t item = (size_t)fl * L.stage_stride + L.slot_base + slot;
+    L.stage[item] = make_float4(ro.x, ro.y, ro.z, u2f(sa));
+    if (!RNG::kShadowSubstream) L.approach_aux[item] = sb;   // sampler.h: the second word of its state
     if (L.counters)
     {
         if (n_steps) atomicAdd(&L.counters[1], n_steps);   // density lookups and bound lookups the estimator makes on this stretch
@@ -1962,12 +1967,14 @@ void launch_approach(const SceneDev& S, const LaunchDev& L, int est, int rng, bo
     else if (quant)
     {
         if (rng == RNG_PHILOX7) hipLaunchKernelGGL((approach_local_k<RngPhilox7, true>), grid, dim3(256), 0, st, S, L);
-        else hipLaunchKernelGGL((approach_local_k<RngPhilox, true>), grid, dim3(256), 0, st, S, L);
+        else if (rng == RNG_PHILOX) hipLaunchKernelGGL((approach_local_k<RngPhilox, true>), grid, dim3(256), 0, st, S, L);
+        else hipLaunchKernelGGL((approach_local_k<RngSamplerH, true>), grid, dim3(256), 0, st, S, L);
     }
     else
     {
         if (rng == RNG_PHILOX7) hipLaunchKernelGGL((approach_local_k<RngPhilox7, false>), grid, dim3(256), 0, st, S, L);
-        else hipLaunchKernelGGL((approach_local_k<RngPhilox, false>), grid, dim3(256), 0, st, S, L);
+        else if (rng == RNG_PHILOX) hipLaunchKernelGGL((approach_local_k<RngPhilox, false>), grid, dim3(256), 0, st, S, L);
+        else hipLaunchKernelGGL((approach_local_k<RngSamplerH, false>), grid, dim3(256), 0, st, S, L);
     }
 }
 void launch_pixel_lists(unsigned width, unsigned height, unsigned rank, unsigned world, unsigned ntiles, const unsigned* d_row_start,

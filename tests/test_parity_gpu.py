@@ -76,10 +76,10 @@ def test_julia32_frames_bit_exact(vp, oracle, est, rng_mode):
 
 
 @pytest.mark.parametrize("est,brick", [(0, 1), (1, 1), (1, 8)])
-@pytest.mark.parametrize("rng_mode", [1, 2])
+@pytest.mark.parametrize("rng_mode", [0, 1, 2])
 def test_approach_kernels_walk_the_estimators_steps(vp, oracle, est, brick, rng_mode, monkeypatch):
-    """approach_k / approach_local_k walk the camera rays through their certified-empty stretch ahead of the integrator (counter-based
-    streams, staged launches).  A counting launch makes those steps in the integrator itself unless VP_COUNT_APPROACH is set; with
+    """approach_k / approach_local_k walk the camera rays through their certified-empty stretch ahead of the integrator (staged
+    launches; the hand-over carries the stream's state: a pair index, or sampler.h's two words).  A counting launch makes those steps in the integrator itself unless VP_COUNT_APPROACH is set; with
     it the walk's steps and segments are tallied by the approach kernels: image and work counters == oracle either way, and
     the integrator is left with fewer density lookups of its own than the estimator makes."""
     grid = oracle.julia(64)
