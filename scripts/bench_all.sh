@@ -8,4 +8,5 @@ $B --workload c3 > gpurun_out/bench_r03_c3.json 2>/dev/null
 $B --workload c3ref > gpurun_out/bench_r03_c3ref.json 2>/dev/null
 $B --workload c4s > gpurun_out/bench_r03_c4s.json 2>/dev/null
 $B --workload c4f > gpurun_out/bench_r03_c4f.json 2>/dev/null
+$B --workload c3ref --rng samplerh > gpurun_out/bench_r03_c3ref_samplerh.json 2>/dev/null
 python bench.py > gpurun_out/bench_r03_final.json 2>/dev/null
