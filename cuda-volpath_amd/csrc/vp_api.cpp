@@ -824,14 +824,23 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     // the camera rays' free flights through certified-empty cells in kernels of their own (approach_k: global majorant, any stream;
     // approach_local_k: decomposition estimator, counter-based streams), where a null collision in empty space leaves a
     // throughput of 1 unchanged
-    bool approach = false;
+    bool approach = false, approach_thr = false;
     if (G.use_approach && (G.est == VP_EST_GLOBAL || (G.est == VP_EST_DECOMP && G.use_approach_local)) && !G.trk && !G.env_mis && L.crawl && G.n_general &&
         (!G.count || getenv("VP_COUNT_APPROACH")))   // counting launches: the integrator makes every step itself unless asked (block tallies)
     {
         // global majorant: one majorant for the whole walk, checked here; decomposition: approach_local_k checks each segment's own
-        if (G.est == VP_EST_GLOBAL) rc = ensure_light_identity(p, &approach);
-        else approach = true;
+        bool identity = true;
+        if (G.est == VP_EST_GLOBAL) rc = ensure_light_identity(p, &identity);
         if (rc) return rc;
+        approach = true;
+        if (!identity)
+        {
+            // the walk's null collisions change the throughput: render_k looks it up by their number (the light kernel's table)
+            rc = ensure_thr_table(p, &L.thr_table);
+            if (rc) return rc;
+            L.thr_n  = G.thr_entries;
+            approach_thr = true;
+        }
     }
     const size_t per_frame = sh.per_frame;
     if (0xfffffff0u / per_frame < 1) return fail(VP_E_ARG, "image too large for the 32-bit sample queue");
@@ -985,7 +994,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                 }
                 if (approach && aux_ok && L.stage && f <= 65535)
                 {
-                    L.approach       = 1;
+                    L.approach       = approach_thr ? 2u : 1u;
                     L.approach_steps = G.approach_steps;
                     launch_approach(S, L, G.est, G.rng, G.quant, T.stream);
                     le = hipGetLastError();

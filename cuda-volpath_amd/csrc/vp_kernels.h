@@ -102,7 +102,7 @@ struct LaunchDev
     // of this launch through its certified-empty stretch already and left (distance reached, draw pairs used) / (segment origin, pairs
     // used) in the sample's staging slot; the integrator takes a new sample up from there.  0 = start as the reference does.
     unsigned* approach_aux;   // sampler.h + decomposition: the second word of the stream's state per staging slot (the slot holds four)
-    unsigned approach;
+    unsigned approach;        // 1: the walk's null collisions leave the throughput at 1; 2 (global majorant): look it up by their number in thr_table
     unsigned approach_steps;  // most free-flight steps (restart segments) the walk makes per sample (the integrator does what is left)
 };
 

@@ -620,10 +620,26 @@ void render_k(SceneDev S, LaunchDev L)
                                 if (!LIGHT) t_empty = L.crawl ? L.crawl[2 * ((size_t)px + (size_t)py * P.width) + 1].x : 0.0f;
                                 if (APPR && L.approach)
                                 {
-                                    const float4 a = L.stage[item];   // approach_k: distance reached, where the stream stands
+                                    const float4 a = L.stage[item];   // approach_k: distance reached, where the stream stands, steps made
                                     dist  = a.x;
                                     rng.load(f2u(a.y), f2u(a.z));
                                     fresh = true;
+                                    if (L.approach == 2u)
+                                    {
+                                        // a medium whose null collision in empty space is not exactly neutral: the throughput after the
+                                        // walk's n of them is the n-th iterate of one function of one float (thr_table_k, as the light
+                                        // kernel of this estimator looks it up; beyond the table the recurrence is run)
+                                        const unsigned n = f2u(a.w), last = L.thr_n - 1u;
+                                        float t = L.thr_table[n < last ? n : last];
+                                        if (n > last)
+                                        {
+                                            const float s0  = hyperion_s(0 - 5);
+                                            const float stp = max_sig * ((1.0f - s0) * density + s0 * density * (1.0f - P.g));
+                                            const float inv = 1.0f / stp;
+                                            for (unsigned k = last; k < n; k++) t = null_collision_in_empty_space(t, stp, inv);
+                                        }
+                                        thr = f3{t, t, t};
+                                    }
                                 }
                                 if (LOCAL && L.crawl)
                                 {
@@ -1457,7 +1473,7 @@ __global__ __launch_bounds__(256) void approach_k(SceneDev S, LaunchDev L)
             rng.save(sa, sb);
         }
     }
-    L.stage[(size_t)fl * L.stage_stride + L.slot_base + slot] = make_float4(dist, u2f(sa), u2f(sb), 0.0f);
+    L.stage[(size_t)fl * L.stage_stride + L.slot_base + slot] = make_float4(dist, u2f(sa), u2f(sb), u2f(pairs));
     if (L.counters && pairs) atomicAdd(&L.counters[1], (unsigned long long)pairs);   // density lookups the estimator makes on these steps
 }
 

@@ -75,15 +75,17 @@ def test_julia32_frames_bit_exact(vp, oracle, est, rng_mode):
     buf.free()
 
 
-@pytest.mark.parametrize("est,brick", [(0, 1), (1, 1), (1, 8)])
+@pytest.mark.parametrize("est,brick,density", [(0, 1, 800.0), (0, 1, 209.0), (1, 1, 800.0), (1, 8, 800.0), (1, 8, 209.0)])
 @pytest.mark.parametrize("rng_mode", [0, 1, 2])
-def test_approach_kernels_walk_the_estimators_steps(vp, oracle, est, brick, rng_mode, monkeypatch):
+def test_approach_kernels_walk_the_estimators_steps(vp, oracle, est, brick, density, rng_mode, monkeypatch):
     """approach_k / approach_local_k walk the camera rays through their certified-empty stretch ahead of the integrator (staged
     launches; the hand-over carries the stream's state: a pair index, or sampler.h's two words).  A counting launch makes those steps in the integrator itself unless VP_COUNT_APPROACH is set; with
     it the walk's steps and segments are tallied by the approach kernels: image and work counters == oracle either way, and
-    the integrator is left with fewer density lookups of its own than the estimator makes."""
+    the integrator is left with fewer density lookups of its own than the estimator makes.  Density 209: a majorant whose null
+    collision in empty space is one ulp off neutral -- the global-majorant integrator then looks the walked throughput up by the
+    number of steps, the decomposition walk stops at the first segment whose majorant is not neutral."""
     grid = oracle.julia(64)
-    osc, oP, vP = _setup(vp, oracle, grid, est, rng_mode, brick=brick, key=(31, 7))
+    osc, oP, vP = _setup(vp, oracle, grid, est, rng_mode, brick=brick, key=(31, 7), P_kw=dict(density=density))
     if est == 1:
         osc.precompute_opacity()
         vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
