@@ -821,9 +821,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         if (rc) return rc;
         L.thr_n = G.thr_entries;
     }
-    // the camera rays' free flights through certified-empty cells in kernels of their own (approach_k: global majorant, any stream;
-    // approach_local_k: decomposition estimator, counter-based streams), where a null collision in empty space leaves a
-    // throughput of 1 unchanged
+    // the camera rays' free flights through certified-empty cells in kernels of their own, ahead of the integrator (approach_k: global
+    // majorant; approach_local_k: decomposition estimator; spectral tracking, passive environment, staged launches)
     bool approach = false, approach_thr = false;
     if (G.use_approach && (G.est == VP_EST_GLOBAL || (G.est == VP_EST_DECOMP && G.use_approach_local)) && !G.trk && !G.env_mis && L.crawl && G.n_general &&
         (!G.count || getenv("VP_COUNT_APPROACH")))   // counting launches: the integrator makes every step itself unless asked (block tallies)
