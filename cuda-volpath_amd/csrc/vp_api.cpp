@@ -887,7 +887,10 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         // the fork point of the light kernel's auxiliary stream: BEFORE the general kernel is queued (the two run side by side),
         // after the queue heads are zeroed; an event of its own, created on first use
         // (the same fork serves the helper workgroups of the LDS-table kernel, below, when no light kernel needs the stream)
-        const bool lds_helper = lds_bounds && G.lds_helper && G.n_general && !(G.n_light && !light_const);
+        // (not for look-ahead batches: two of them overlap -- the next one's approach walk and first workgroups run beside the current
+        // one's body and tail -- only if the current one leaves registers free: four LDS-table waves per SIMD do, the helper's fifth does
+        // not.  C3 host loop 1301 -> 1510 Msamples/s without it, profiles/r03_render_kernel_lookahead.txt)
+        const bool lds_helper = lds_bounds && G.lds_helper && G.n_general && !(G.n_light && !light_const) && !tgt;
         bool fork_recorded = false;
         if ((G.n_light && G.n_general && !light_const && G.light_overlap) || lds_helper)
         {
