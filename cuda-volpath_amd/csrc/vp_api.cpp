@@ -132,6 +132,7 @@ struct State
     size_t      appr_aux_bytes[3] = {0, 0, 0};
     bool        use_approach_local = true;    // ... and approach_local_k ahead of the decomposition estimator (VP_NO_APPROACH_LOCAL=1: off)
     bool        use_approach = true;          // approach_k ahead of the global-majorant integrator (VP_NO_APPROACH=1: off)
+    unsigned    approach_fshift_max = 6;      // a wave of the approach kernels = one pixel x 2^6 frames (VP_APPROACH_FRAMES_LOG2: 0 = 64 pixels of one frame)
     unsigned    approach_steps = 1u << 20;    // its step cap per sample (VP_APPROACH_STEPS)
     unsigned*   d_light_flag = nullptr;   // [0] the flag, [1..8] the bytes that occur as maxima in the bound table
     bool        bound_mask_valid = false;
@@ -255,6 +256,7 @@ int ensure_device()
     if (knob("VP_NO_LIGHT_CONST", 0, 1, v)) G.use_light_const = v == 0;
     if (knob("VP_NO_APPROACH", 0, 1, v)) G.use_approach = v == 0;
     if (knob("VP_NO_APPROACH_LOCAL", 0, 1, v)) G.use_approach_local = v == 0;
+    if (knob("VP_APPROACH_FRAMES_LOG2", 0, 6, v)) G.approach_fshift_max = (unsigned)v;
     if (knob("VP_APPROACH_STEPS", 0, 1 << 30, v)) G.approach_steps = (unsigned)v;
     if (knob("VP_NO_LIGHT", 0, 1, v)) G.use_light = v == 0;
     if (knob("VP_NO_LIGHT_OVERLAP", 0, 1, v)) G.light_overlap = v == 0;
@@ -998,6 +1000,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                 {
                     L.approach       = approach_thr ? 2u : 1u;
                     L.approach_steps = G.approach_steps;
+                    L.approach_fshift = 0;
+                    while (L.approach_fshift < G.approach_fshift_max && (2u << L.approach_fshift) <= (unsigned)f) L.approach_fshift++;
                     launch_approach(S, L, G.est, G.rng, G.quant, T.stream);
                     le = hipGetLastError();
                     // the helper workgroups of the LDS-table kernel (auxiliary stream, below) read the staging slots as well: their

@@ -103,6 +103,7 @@ struct LaunchDev
     // used) in the sample's staging slot; the integrator takes a new sample up from there.  0 = start as the reference does.
     unsigned* approach_aux;   // sampler.h + decomposition: the second word of the stream's state per staging slot (the slot holds four)
     unsigned approach;        // 1: the walk's null collisions leave the throughput at 1; 2 (global majorant): look it up by their number in thr_table
+    unsigned approach_fshift; // log2 of the frames a wave of the approach kernels spans (6 where the launch has 64 frames or more)
     unsigned approach_steps;  // most free-flight steps (restart segments) the walk makes per sample (the integrator does what is left)
 };
 

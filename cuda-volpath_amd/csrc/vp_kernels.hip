@@ -1441,8 +1441,12 @@ __global__ __launch_bounds__(256) void miss_fill_k(SceneDev S, LaunchDev L, int 
 template <class RNG>
 __global__ __launch_bounds__(256) void approach_k(SceneDev S, LaunchDev L)
 {
-    const unsigned slot = blockIdx.x * 256u + threadIdx.x, fl = blockIdx.y;
-    if (slot >= L.nslots) return;
+    // a wave = ONE pixel in 64 consecutive frames where the launch has that many (fewer frames: 2^k frames x 64 / 2^k pixels): the
+    // lanes share the ray, its certificate and the bricks it crosses, and differ only in what they draw -- their walks have
+    // the same length up to the noise of a sum of exponentials
+    const unsigned sh   = L.approach_fshift;
+    const unsigned slot = blockIdx.x * (256u >> sh) + (threadIdx.x >> sh), fl = (blockIdx.y << sh) + (threadIdx.x & ((1u << sh) - 1u));
+    if (slot >= L.nslots || fl >= (unsigned)L.nframes) return;
     const ParamDev& P = L.P;
     const unsigned pix = L.pixels[slot], px = pix & 0xffffu, py = pix >> 16;
     if (px >= P.width || py >= P.height) return;   // a partial edge tile: render_k skips the slot as well
@@ -1486,8 +1490,9 @@ __global__ __launch_bounds__(256) void approach_k(SceneDev S, LaunchDev L)
 template <class RNG, bool QUANT>
 __global__ __launch_bounds__(256) void approach_local_k(SceneDev S, LaunchDev L)
 {
-    const unsigned slot = blockIdx.x * 256u + threadIdx.x, fl = blockIdx.y;
-    if (slot >= L.nslots) return;
+    const unsigned sh   = L.approach_fshift;   // (a wave = one pixel in 2^sh frames, as in approach_k)
+    const unsigned slot = blockIdx.x * (256u >> sh) + (threadIdx.x >> sh), fl = (blockIdx.y << sh) + (threadIdx.x & ((1u << sh) - 1u));
+    if (slot >= L.nslots || fl >= (unsigned)L.nframes) return;
     const ParamDev& P = L.P;
     const unsigned pix = L.pixels[slot], px = pix & 0xffffu, py = pix >> 16;
     if (px >= P.width || py >= P.height) return;
@@ -1973,7 +1978,8 @@ void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimato
 }
 void launch_approach(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, hipStream_t st)
 {
-    const dim3 grid((L.nslots + 255u) / 256u, (unsigned)L.nframes);
+    const unsigned sh = L.approach_fshift, spb = 256u >> sh;   // pixel slots per workgroup
+    const dim3 grid((L.nslots + spb - 1u) / spb, ((unsigned)L.nframes + (1u << sh) - 1u) >> sh);
     if (est == EST_GLOBAL)
     {
         if (rng == RNG_PHILOX7) hipLaunchKernelGGL(approach_k<RngPhilox7>, grid, dim3(256), 0, st, S, L);
