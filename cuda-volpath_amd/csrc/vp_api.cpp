@@ -130,6 +130,7 @@ struct State
     bool        use_light_const = true;
     unsigned*   d_appr_aux[3] = {nullptr, nullptr, nullptr};   // per render target (caller's stream, two look-ahead slots): LaunchDev::approach_aux
     size_t      appr_aux_bytes[3] = {0, 0, 0};
+    int         last_approach = 0;            // vp_last_approach_mode
     bool        use_approach_local = true;    // ... and approach_local_k ahead of the decomposition estimator (VP_NO_APPROACH_LOCAL=1: off)
     bool        use_approach = true;          // approach_k ahead of the global-majorant integrator (VP_NO_APPROACH=1: off)
     unsigned    approach_fshift_max = 6;      // a wave of the approach kernels = one pixel x 2^6 frames (VP_APPROACH_FRAMES_LOG2: 0 = 64 pixels of one frame)
@@ -980,6 +981,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             {
                 ClassTimer ct(0, T.stream);
                 L.approach = 0;
+                G.last_approach = 0;
                 bool aux_ok = true;
                 if (approach && L.stage && G.est == VP_EST_DECOMP && G.rng == VP_RNG_SAMPLERH)
                 {
@@ -1004,6 +1006,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                     while (L.approach_fshift < G.approach_fshift_max && (2u << L.approach_fshift) <= (unsigned)f) L.approach_fshift++;
                     launch_approach(S, L, G.est, G.rng, G.quant, T.stream);
                     le = hipGetLastError();
+                    G.last_approach = (int)L.approach;
                     // the helper workgroups of the LDS-table kernel (auxiliary stream, below) read the staging slots as well: their
                     // fork point moves behind the walk
                     if (lds_helper && fork_recorded && le == hipSuccess)
@@ -1538,6 +1541,7 @@ int vp_render_time_ms(double* total_ms, int* launches, int reset)
     }
     return VP_OK;
 }
+int vp_last_approach_mode(void) { return G.last_approach; }
 int vp_render_class_time_ms(double ms[3], unsigned pixels[3], int reset)
 {
     int rc = ensure_device();

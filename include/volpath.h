@@ -196,6 +196,12 @@ int vp_render_time_ms(double* total_ms, int* launches, int reset);
  * kernel on the stream it runs on (the first two run side by side, so the times overlap).  pixels[] = the pixels of each class
  * in the current lists of this context.  Either pointer may be NULL.  Synchronises. */
 int vp_render_class_time_ms(double ms[3], unsigned pixels[3], int reset);
+
+/* How the last render launch of this context took its general pixels' camera rays to the medium: 0 = the integrator walked them
+ * itself (one-frame launches, counting launches, scalar / MIS builds, VP_NO_APPROACH), 1 = approach_k / approach_local_k walked the
+ * certified-empty stretch ahead of it, 2 = as 1 with the walked throughput looked up by the number of steps (a global-majorant
+ * medium whose null collision in empty space is not neutral).  Never changes a result. */
+int vp_last_approach_mode(void);
 /* Builds everything a render of this Param would build first -- the per-pixel tables of the current camera, the pixel lists
  * of the shard, the sun table -- and waits for it.  A host that moves the camera may call it to take that work out of its
  * first frame; bench.py times it (per_camera_setup_ms).  Not needed for correctness: render_kernel does the same on demand. */

@@ -92,6 +92,10 @@ def test_approach_kernels_walk_the_estimators_steps(vp, oracle, est, brick, dens
     frames = list(range(7, 13))
     ref, cnt = _oracle_frames(osc, oP, frames)
     buf = vp.DeviceBuffer(W, H)
+    # a plain staged launch uses the walk: mode 2 where the global-majorant medium's null collision is not neutral (density 209)
+    vp.render_frames(buf.ptr, frames[0], len(frames), vP)
+    assert np.array_equal(buf.download(), ref)
+    assert vp.last_approach_mode() == (2 if (est == 0 and density == 209.0) else 1)
     for walk in (False, True):
         if walk:
             monkeypatch.setenv("VP_COUNT_APPROACH", "1")
@@ -105,6 +109,7 @@ def test_approach_kernels_walk_the_estimators_steps(vp, oracle, est, brick, dens
         assert np.array_equal(got, ref), (walk, float(np.abs(got - ref).max()))
         for k in ("samples", "density_lookups", "bound_lookups", "opacity_lookups", "env_lookups", "scatters"):
             assert c[k] == cnt[k], (walk, k, c[k], cnt[k])
+        assert (vp.last_approach_mode() != 0) == walk
     buf.free()
 
 
