@@ -650,6 +650,7 @@ def test_full_size_workloads_match_the_oracle_on_sampled_pixels(vp, oracle, work
     vp.render_frames(buf.ptr, first, frames, P)
     got = buf.download()
     buf.free()
+    assert vp.last_approach_mode() == 1          # the camera rays were walked ahead of the integrator (approach_k / approach_local_k)
     cls = vp.pixel_table(P)[..., 5].astype(int)
     rng = np.random.default_rng(5)
     pick = []
