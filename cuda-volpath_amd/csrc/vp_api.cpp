@@ -137,6 +137,11 @@ struct State
     unsigned    approach_steps = 1u << 20;    // its step cap per sample (VP_APPROACH_STEPS)
     unsigned*   d_light_flag = nullptr;   // [0] the flag, [1..8] the bytes that occur as maxima in the bound table
     bool        bound_mask_valid = false;
+    unsigned    h_bound_mask[8] = {};     // ... read back (ensure_bound_mask)
+    // exit flights (render_k): per cell and class of directions, is every cell such a ray can meet empty?  Built with the volume
+    bool        use_exit    = true;       // VP_NO_EXIT=1: every path walks to the box exit
+    unsigned    exit_k      = 8;          // null collisions in empty space before a lane asks for the test (VP_EXIT_K)
+    unsigned char* d_exit   = nullptr;
     float       light_key[7] = {};
     unsigned long long light_epoch = ~0ull;
     bool        light_const = false;
@@ -268,6 +273,8 @@ int ensure_device()
     if (knob("VP_THR_TABLE", 2, 1 << 20, v)) G.thr_entries = (unsigned)v;
     if (knob("VP_LOOKAHEAD", 0, 4096, v)) G.la_max = (int)v;
     if (knob("VP_NO_LA_CANCEL", 0, 1, v)) G.la_cancel = v == 0;
+    if (knob("VP_NO_EXIT", 0, 1, v)) G.use_exit = v == 0;
+    if (knob("VP_EXIT_K", 1, VP_EXIT_TRIP, v)) G.exit_k = (unsigned)v;
     G.dev_ready = true;
     return VP_OK;
 }
@@ -286,6 +293,8 @@ int free_volume()
     G.d_danger = nullptr;
     if (G.d_sunclip) HIPCHK(hipFree(G.d_sunclip));
     G.d_sunclip = nullptr; G.sunclip_key.clear();
+    if (G.d_exit) HIPCHK(hipFree(G.d_exit));
+    G.d_exit = nullptr;
     G.d_cells = G.d_bounds = nullptr;
     G.d_opacity   = nullptr;
     G.S.cells_u8  = nullptr;
@@ -397,6 +406,13 @@ int do_init_volume_(const void* h_volume, vp_extent ext, bool quantized, const v
         HIPCHK(hipGetLastError());
     }
     else { (void)hipGetLastError(); G.d_danger = nullptr; }  // no memory for it: the estimator fetches every cell, same bits
+    // ... and of the direction table of the exit flights
+    if (G.d_danger && G.use_exit && hipMalloc((void**)&G.d_exit, 3 * n) == hipSuccess)
+    {
+        launch_exit_table(G.d_danger, G.d_exit, nx, ny, nz, G.stream);
+        HIPCHK(hipGetLastError());
+    }
+    else { (void)hipGetLastError(); G.d_exit = nullptr; }   // none: every path walks to the box exit, same bits
     G.bound_mask_valid = false;
     HIPCHK(hipStreamSynchronize(G.stream));  // caller may free h_volume on return (host.cpp:1343); scratch freed by the guard
     S.linear      = G.linear ? 1 : 0;
@@ -658,6 +674,46 @@ int ensure_light_const(const Param* p, bool* out)
     if (!G.use_light_const || G.count) return VP_OK;   // (the counting build walks the light paths: its counters are the estimator's)
     return ensure_light_identity(p, out);
 }
+// the bytes that occur as maxima in the (uchar) bound table: 256 bits on the device (d_light_flag + 1) and on the host
+int ensure_bound_mask()
+{
+    if (G.bound_mask_valid) return VP_OK;
+    if (!G.d_light_flag) HIPCHK(hipMalloc((void**)&G.d_light_flag, 9 * sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(G.d_light_flag + 1, 0, 8 * sizeof(unsigned), G.stream));
+    launch_bound_bytes((const unsigned char*)G.d_bounds, (size_t)G.S.bnx * G.S.bny * G.S.bnz, G.d_light_flag + 1, G.stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(G.h_bound_mask, G.d_light_flag + 1, sizeof G.h_bound_mask, hipMemcpyDeviceToHost, G.stream));
+    HIPCHK(hipStreamSynchronize(G.stream));
+    G.bound_mask_valid = true;
+    return VP_OK;
+}
+// Exit flights (vp_kernels.hip render_k): which launches may end a path that can only leave the box.  Spectral tracking,
+// passive environment, trilinear fetches (the emptiness certificate is stated for them), not the bounded estimator (it counts
+// segments); local majorants: a uchar bound table with at most four distinct maxima (the Julia grids have two: 0 and 255) -- the
+// test checks every majorant a segment through empty cells can have.
+int exit_flights(LaunchDev& L)
+{
+    L.exit_oct = nullptr; L.exit_start = -(1 << 30); L.exit_nbytes = 0; L.exit_bytes = 0;
+    if (!G.use_exit || !G.d_exit || !G.linear || G.trk || G.env_mis || G.est == VP_EST_BOUNDED) return VP_OK;
+    if (G.est != VP_EST_GLOBAL)
+    {
+        if (!G.quant) return VP_OK;
+        int rc = ensure_bound_mask();
+        if (rc) return rc;
+        unsigned nb = 0, packed = 0;
+        for (unsigned b = 0; b < 256; b++)
+            if (G.h_bound_mask[b >> 5] >> (b & 31u) & 1u)
+            {
+                if (nb < 4) packed |= b << (8u * nb);
+                nb++;
+            }
+        if (nb == 0 || nb > 4) return VP_OK;
+        L.exit_nbytes = nb; L.exit_bytes = packed;
+    }
+    L.exit_oct   = G.d_exit;
+    L.exit_start = VP_EXIT_TRIP - (int)G.exit_k;
+    return VP_OK;
+}
 // the check itself; also what approach_k rests on (a null collision in empty space leaves a throughput of 1 as it is)
 int ensure_light_identity(const Param* p, bool* out)
 {
@@ -669,12 +725,10 @@ int ensure_light_identity(const Param* p, bool* out)
     if (G.light_epoch != G.epoch || memcmp(key, G.light_key, sizeof key) != 0)
     {
         if (!G.d_light_flag) HIPCHK(hipMalloc((void**)&G.d_light_flag, 9 * sizeof(unsigned)));
-        if (local && !G.bound_mask_valid)
+        if (local)
         {
-            HIPCHK(hipMemsetAsync(G.d_light_flag + 1, 0, 8 * sizeof(unsigned), G.stream));
-            launch_bound_bytes((const unsigned char*)G.d_bounds, (size_t)G.S.bnx * G.S.bny * G.S.bnz, G.d_light_flag + 1, G.stream);
-            HIPCHK(hipGetLastError());
-            G.bound_mask_valid = true;
+            int rcm = ensure_bound_mask();
+            if (rcm) return rcm;
         }
         const unsigned one = 1u;
         unsigned flag = 0u;
@@ -812,6 +866,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     rc = ensure_sun_clip(&L.sun_clip, &L.clip_ds);
     if (rc) return rc;
     L.count_clips = getenv("VP_DEBUG_COUNT_CLIPS") ? 1u : 0u;
+    rc = exit_flights(L);
+    if (rc) return rc;
     bool light_const = false;
     if (G.n_light)
     {
@@ -1509,9 +1565,10 @@ int vp_read_counters(vp_counters* out, int reset)
     }
         if (getenv("VP_DEBUG_COUNTERS"))
         {
-            static const char* names[14] = {"setup", "half-step", "lookup+collision", "segment/ray end", "scatter", "nee", "phase", "background", "write", "refill", "global set-up", "fetch", "zero fetch (path)", "zero fetch (shadow)"};
+            static const char* names[15] = {"setup", "half-step", "lookup+collision", "segment/ray end", "scatter", "nee", "phase", "background", "write", "refill", "global set-up", "fetch", "zero fetch (path)", "zero fetch (shadow)", "exit test"};
+            fprintf(stderr, "[vp] exit flights: %llu tests, %llu paths ended; %llu null collisions in empty space on flights that WALKED out of the box (global majorant)\n", h[13], h[15], h[14]);
             fprintf(stderr, "[vp] block: wave executions, lanes per execution (of 64)\n");
-            for (int b = 0; b < 14; b++)
+            for (int b = 0; b < 15; b++)
                 if (h[16 + 2 * b]) fprintf(stderr, "[vp]   %-18s %14llu  %5.1f\n", names[b], h[16 + 2 * b], (double)h[17 + 2 * b] / (double)h[16 + 2 * b]);
         }
     if (reset) HIPCHK(hipMemset(G.d_counters, 0, sizeof h));
@@ -1644,6 +1701,18 @@ int vp_get_pixel_table(const Param* p, float* dst, size_t count)
     if (rc) return rc;
     if (!t) return fail(VP_E_STATE, "no pixel table in this configuration (point filtering, or the tables are switched off)");
     HIPCHK(hipMemcpy(dst, t, need * sizeof(float), hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+int vp_get_exit_table(unsigned char* dst, size_t count)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!G.have_volume) return fail(VP_E_STATE, "vp_get_exit_table needs a volume");
+    const size_t n = 3 * (size_t)G.S.nx * G.S.ny * G.S.nz;
+    if (!dst || count < n) return fail(VP_E_ARG, "exit table needs %zu bytes", n);
+    if (!G.d_exit) return fail(VP_E_STATE, "no exit table in this configuration (switched off, or no memory)");
+    HIPCHK(hipStreamSynchronize(G.stream));
+    HIPCHK(hipMemcpy(dst, G.d_exit, n, hipMemcpyDeviceToHost));
     return VP_OK;
 }
 int vp_get_sun_clip_table(unsigned short* dst, size_t count, float* step)

@@ -53,6 +53,8 @@
 #ifndef VP_STEPS_PER_PASS
 #define VP_STEPS_PER_PASS 4
 #endif
+// exit flights: the lane counter value from which a lane is tested
+#define VP_EXIT_TRIP 64
 
 namespace vp
 {
@@ -105,6 +107,16 @@ struct LaunchDev
     unsigned approach;        // 1: the walk's null collisions leave the throughput at 1; 2 (global majorant): look it up by their number in thr_table
     unsigned approach_fshift; // log2 of the frames a wave of the approach kernels spans (6 where the launch has 64 frames or more)
     unsigned approach_steps;  // most free-flight steps (restart segments) the walk makes per sample (the integrator does what is left)
+    // Exit flights (render_k).  A path that can meet certified-empty cells only on its way out of the box, and whose null collisions
+    // there leave its throughput bit for bit as it is, ends with the environment whatever it draws: it is ended at once.
+    // exit_oct: three byte planes (one per dominant axis of a direction in cell units), per cell eight bits, one per class of signs:
+    // every cell of the quarter pyramid that opens from this cell in that class of directions has no non-empty cell in its 3x3x3
+    // neighbourhood (exit_dir_slice_k); null = off.
+    const unsigned char* exit_oct;
+    int      exit_start;      // a lane counts its null collisions in empty space from here and is tested from VP_EXIT_TRIP on:
+                              // VP_EXIT_TRIP - K (VP_EXIT_K); far below zero when the test is off
+    unsigned exit_nbytes;     // local-majorant estimators: how many distinct bytes occur as maxima in the bound table (1..4, else off) ...
+    unsigned exit_bytes;      // ... and the bytes, packed: every majorant a segment in empty cells can have
 };
 
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
@@ -133,6 +145,8 @@ void launch_danger(const SceneDev& S, bool quant, unsigned char* out, hipStream_
 float sun_clip_step(const SceneDev& S);  // the table's distance unit: a quarter of the smallest cell edge
 void launch_sun_clip(const SceneDev& S, const unsigned char* danger, float ds, unsigned short* out, hipStream_t st);
 void launch_empty_table(const SceneDev& S, unsigned width, unsigned height, const unsigned char* danger, float4* table, hipStream_t st);
+// the direction table of the exit flights from the danger volume: planes = 3 * nx*ny*nz bytes; one small kernel per slice and direction
+void launch_exit_table(const unsigned char* danger, unsigned char* planes, int nx, int ny, int nz, hipStream_t st);
 void launch_reduce(const LaunchDev& L, hipStream_t st);
 // bricks: cells in 4x4x4 bricks (vp_device.h cell_index); the buffer then holds ceil(n/4)^3 * 64 cells
 void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, bool bricks, hipStream_t st);

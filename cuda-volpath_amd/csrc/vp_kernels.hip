@@ -62,6 +62,18 @@ __device__ __forceinline__ float null_collision_in_empty_space(float t, float si
     float Pn = (mn + mn) + mn;
     return t * (sigma_t_prime * wdiv_(inv_sigma_t * Pn, Pn));
 }
+// Does a null collision where the density is +0 leave the throughput (t.x, t.y, t.z) bit for bit as it is, whatever is drawn?  The
+// spectral tracker's expressions (kernel.cu:2107-2134; tracking_step below) with sigma_t_den = +0 -- sigma_c = 0: no control
+// component where the cells are empty --: Ps = |0 t.x| + |0 t.y| + |0 t.z| must be +0 (then `real`, e * c < Ps, is false for any
+// draw e), and the factor every channel is multiplied by, sigma_null * f = sigma_t' * ((inv_sigma_t * c) / Pn), must be exactly 1.
+// The one-channel (ACH) form of the step computes the same sums ((m + m) + m) from one product.
+__device__ __forceinline__ bool null_collision_is_identity(f3 t, float sigma_t_prime, float inv_sigma_t)
+{
+    const float Ps = __builtin_fabsf(0.0f * t.x) + __builtin_fabsf(0.0f * t.y) + __builtin_fabsf(0.0f * t.z);
+    const float Pn = __builtin_fabsf(sigma_t_prime * t.x) + __builtin_fabsf(sigma_t_prime * t.y) + __builtin_fabsf(sigma_t_prime * t.z);
+    const float c  = Ps + Pn;
+    return Ps == 0.0f && sigma_t_prime * wdiv_(inv_sigma_t * c, Pn) == 1.0f;
+}
 // table[n] = throughput of an unscattered path of the global-majorant estimator after n null collisions in empty space: it
 // starts at (1,1,1) and every sample has the same sigma_t' (segment set-up of __d_render with no scatter behind it,
 // kernel.cu:1355-1366), so the sequence is the same for every sample of a launch.  One thread, `count` dependent steps.
@@ -171,6 +183,15 @@ void render_k(SceneDev S, LaunchDev L)
     constexpr bool APPR = EST == EST_GLOBAL && TRK == 0 && !LIGHT && !MIS;   // (any stream: the hand-over carries its state)
     // decomposition estimator: the same for the restart segments that end before the certified-empty distance (approach_local_k)
     constexpr bool APPR_L = EST == EST_DECOMP && TRK == 0 && !LIGHT && !MIS;
+    // Exit flights.  A path in empty space that can do nothing but leave the box -- every cell its ray can still meet is certified
+    // empty (L.exit_oct: the quarter pyramid of cells that opens from its cell along the direction's dominant axis) and a null collision
+    // there leaves its throughput bit for bit as it is (null_collision_is_identity) -- ends with the environment along its direction
+    // whatever it draws on the way (no draw is used after a path's end; the heat channel counts scatters): it goes to EV_BG at once
+    // instead of walking there at 800 null collisions per unit length (38 % of the lane-steps of BASELINE config 2's general class).
+    // A lane counts its null collisions in empty space in `terms` (free while no shadow ray is tracked); whenever its wave is in the
+    // event pass anyway, lanes that have counted K are tested: one byte load, no loop, no parking.  Not for the bounded estimator (its
+    // heat channel counts the segments of that walk), the scalar builds and MIS.
+    constexpr bool EXITC = TRK == 0 && !MIS && !LIGHT && EST != EST_BOUNDED && (QUANT || EST == EST_GLOBAL);
     const ParamDev& P = L.P;
     const f3    sig_t     = f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]};
     const f3    sig_s     = sig_t * f3{P.albedo[0], P.albedo[1], P.albedo[2]};
@@ -210,13 +231,15 @@ void render_k(SceneDev S, LaunchDev L)
     // COUNT build only: where the timed kernel ends the current sun shadow ray (it walks on here, so that density_lookups stays
     // the estimator's count, and stops counting loads)
     float    t_clip = 1e30f;
-    unsigned long long c_load = 0;
+    bool     ex_clear = false;   // COUNT build only: the timed kernel has ended this path (exit flight); it walks on here, counting no loads
+    unsigned long long c_load = 0, c_xtest = 0, c_xout = 0, c_xok = 0;
+    unsigned zrun = 0;   // COUNT build only: null collisions in empty space of the current flight (c_xout: those of flights that left the box)
 
     unsigned long long c_den = 0, c_bnd = 0, c_opa = 0, c_env = 0, c_sca = 0, c_smp = 0;
     unsigned long long d_iter = 0, d_act = 0, d_outer = 0, d_shadow = 0;  // debug (lane 0 counts wave events)
     unsigned long long t_slow = 0, t_fast = 0, t_mark = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;  // shader cycles
     // COUNT build: how often each code block runs (wave executions) and for how many lanes -- where the lane slots go
-    enum { B_SETUP, B_HALF, B_LOOK, B_EXIT, B_SCATTER, B_NEE, B_HG, B_BG, B_WRITE, B_REFILL, B_GSETUP, B_FETCH, B_ZERO, B_ZERO_SH, B_NBLK };
+    enum { B_SETUP, B_HALF, B_LOOK, B_EXIT, B_SCATTER, B_NEE, B_HG, B_BG, B_WRITE, B_REFILL, B_GSETUP, B_FETCH, B_ZERO, B_ZERO_SH, B_EXITT, B_NBLK };
     unsigned long long bw[B_NBLK] = {}, bl[B_NBLK] = {};
     auto tally = [&](int b, bool on) __attribute__((always_inline)) {
         if (COUNT)
@@ -313,6 +336,7 @@ void render_k(SceneDev S, LaunchDev L)
         };
         auto next_segment = [&]() __attribute__((always_inline)) {
             st = ST_SETUP;
+            if (EXITC) terms = L.exit_start;
             if (EST == EST_GLOBAL) nsc++;
             if (EST == EST_BOUNDED) seg++;
             if ((EST == EST_BOUNDED ? seg : nsc) >= 800) st = EV_WRITE;
@@ -328,7 +352,7 @@ void render_k(SceneDev S, LaunchDev L)
         tally(B_SCATTER, st == EV_SCATTER);
         if (!LIGHT && st == EV_SCATTER)
         {
-            if (COUNT) c_sca++;
+            if (COUNT) { c_sca++; zrun = 0; }
             t_empty = 0.0f;  // the certificate is for the unscattered camera ray only
             if (LOCAL) nsc++;  // num_scatters += !through, kernel.cu:2146
             // "to match passive result": post-increment count (DECOMP :2168) / i-4 (GLOBAL :1465)
@@ -488,6 +512,64 @@ void render_k(SceneDev S, LaunchDev L)
             if (LOCAL) inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
             next_segment();
         }
+        // ---- exit flights: can this path do anything but leave the box?  Lanes in flight whose counter has tripped ride along.
+        if (EXITC)
+        {
+            const bool cand = (st == ST_TRACK || (LOCAL && st == ST_SETUP)) && terms >= VP_EXIT_TRIP;
+            tally(B_EXITT, cand);
+            if (cand)
+            {
+                if (COUNT) c_xtest++;
+                // (1) the cells: every fetch the ray can still make lies in the quarter pyramid of cells that opens from its cell
+                // along the dominant axis of its direction, toward the sides the other two components point to; the table says
+                // whether every cell of that pyramid is empty with empty neighbours (exit_dir_slice_k)
+                const f3 pl = to_local(S, st == ST_TRACK ? ro + rd * dist : ro);
+                int   ci, cj, ck;
+                float w_;
+                axis_linear(pl.x, S.nx, ci, w_);
+                axis_linear(pl.y, S.ny, cj, w_);
+                axis_linear(pl.z, S.nz, ck, w_);
+                // the direction in cell units, its dominant axis A and the signs (A, then the other two in increasing order)
+                const float ex = rd.x * (S.linv[0] * (float)S.nx), ey = rd.y * (S.linv[1] * (float)S.ny), ez = rd.z * (S.linv[2] * (float)S.nz);
+                const float ax = __builtin_fabsf(ex), ay = __builtin_fabsf(ey), az = __builtin_fabsf(ez);
+                const unsigned A   = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
+                const unsigned cls = A == 0u ? ((ex > 0.0f ? 1u : 0u) | (ey > 0.0f ? 2u : 0u) | (ez > 0.0f ? 4u : 0u))
+                                   : A == 1u ? ((ey > 0.0f ? 1u : 0u) | (ex > 0.0f ? 2u : 0u) | (ez > 0.0f ? 4u : 0u))
+                                             : ((ez > 0.0f ? 1u : 0u) | (ex > 0.0f ? 2u : 0u) | (ey > 0.0f ? 4u : 0u));
+                const size_t   ncell = (size_t)S.nx * (size_t)S.ny * (size_t)S.nz;
+                const unsigned bits  = L.exit_oct[(size_t)A * ncell + (size_t)((unsigned)ci + __umul24((unsigned)S.nx, (unsigned)cj + __umul24((unsigned)S.ny, (unsigned)ck)))];
+                bool clear = (bits >> cls) & 1u;
+                // (2) the throughput: every majorant a null collision can meet on the way must leave it as it is: the segment's own
+                // (global majorant); that of every byte that occurs as a maximum in the bound table (local majorants: a segment
+                // through empty cells may still lie in a brick with a positive maximum)
+                bool unit = true;
+                if (clear)
+                {
+                    const f3 t3 = ACH ? f3{thr.x, thr.x, thr.x} : thr;
+                    if (LOCAL)
+                    {
+                        for (unsigned q = 0; q < L.exit_nbytes; q++)
+                        {
+                            const float dm  = fmaxf(0.0001f, (float)((L.exit_bytes >> (8u * q)) & 0xffu) * VP_U8_SCALE);   // segment_setup()
+                            const float stp = max_sig * cur_density * dm;
+                            unit = unit && null_collision_is_identity(t3, stp, 1.0f / stp);
+                        }
+                    }
+                    else
+                        unit = null_collision_is_identity(t3, sigma_t_prime, inv_sigma_t);
+                }
+                if (COUNT && clear && unit) c_xok++;
+                if (clear && unit && !(COUNT && !L.count_clips)) st = EV_BG;
+                else
+                {
+                    // not (yet): the next test comes after another K null collisions in empty space -- much later where the throughput
+                    // was the obstacle (it moves by an ulp per null collision until it meets a fixed point of the factor).  The counting
+                    // build walks on (its density_lookups are the estimator's) and stops counting loads.
+                    if (COUNT && clear && unit) ex_clear = true;
+                    terms = (clear && unit) ? -(1 << 30) : (unit ? L.exit_start : L.exit_start - 4 * VP_EXIT_TRIP);
+                }
+            }
+        }
         // Path ends (environment, write, refill, and the global-majorant set-up of a fresh sample) come one or two lanes at a time:
         // the ~300 instructions of this chain are not run in every visit for them.  They wait -- an idle lane or two -- until
         // end_lanes lanes ask, or four visits have passed, or nothing else is left to do in this wave.
@@ -617,6 +699,8 @@ void render_k(SceneDev S, LaunchDev L)
                                 rad = f3{0.0f, 0.0f, 0.0f};
                                 nsc = 0;
                                 seg = 0;
+                                if (EXITC) terms = L.exit_start;
+                                if (COUNT) ex_clear = false;
                                 if (!LIGHT) t_empty = L.crawl ? L.crawl[2 * ((size_t)px + (size_t)py * P.width) + 1].x : 0.0f;
                                 if (APPR && L.approach)
                                 {
@@ -775,6 +859,7 @@ ends_done:
             const f3 sunp = f3{S2.sun_power[0], S2.sun_power[1], S2.sun_power[2]};
             rad = rad + sunp * (((ACH ? f3{thr.x, thr.x, thr.x} : thr) * ph) * nee_a);
             rd  = pd;
+            if (EXITC) terms = reinterpret_cast<const LaunchDev*>(ka_ + ((sizeof(SceneDev) + alignof(LaunchDev) - 1) / alignof(LaunchDev)) * alignof(LaunchDev))->exit_start;
             if (EST == EST_GLOBAL)
             {
                 nsc++;
@@ -865,6 +950,7 @@ ends_done:
                             ro = ro + rd * t_far;  // tracking restart kernel.cu:2151-2155 / :1809-1813
                             t_empty -= t_far;      // the certified-empty distance is measured from the segment origin
                             st = ST_SETUP;
+                            if (EXITC) terms += d_max <= 0.0001f ? VP_EXIT_TRIP : 0;   // exit flights: a segment through a brick with maximum zero
                             if (EST == EST_BOUNDED && ++seg >= 800) st = EV_WRITE;  // `continue` still counts, :1716
                         }
                         else
@@ -875,7 +961,10 @@ ends_done:
                         }
                     }
                     else
+                    {
                         st = EV_BG;  // transmitted through the box kernel.cu:1444-1452
+                        if (COUNT) { c_xout += zrun; zrun = 0; }
+                    }
                 }
                 else
                 {
@@ -891,7 +980,7 @@ ends_done:
                         if (shadow || !(dist < t_empty))
                         {
                             den = sample_density01<QUANT>(S, p) * cur_density;  // vol_sigma_t kernel.cu:682-695
-                            if (COUNT && !(shadow && dist >= t_clip)) c_load++;
+                            if (COUNT && !(shadow && dist >= t_clip) && !(!shadow && ex_clear)) c_load++;
                         }
                     }
                     else
@@ -901,7 +990,7 @@ ends_done:
                         if (shadow || !(dist < t_empty))
                         {
                             den = sample_density01<QUANT>(S, p) * cur_density;  // vol_sigma_t kernel.cu:682-695
-                            if (COUNT && !(shadow && dist >= t_clip)) c_load++;
+                            if (COUNT && !(shadow && dist >= t_clip) && !(!shadow && ex_clear)) c_load++;
                         }
                     }
                     float e   = rng.next_b();
@@ -949,6 +1038,11 @@ ends_done:
                             ro = p;
                             st = LIGHT ? EV_WRITE : EV_SCATTER;  // (LIGHT: den = +0 makes `real` false)
                         }
+                        else if (EXITC && den == 0.0f)
+                        {
+                            terms++;   // exit flights: a null collision in empty space
+                            if (COUNT) zrun++;
+                        }
                     }
                     else
                     {
@@ -976,6 +1070,11 @@ ends_done:
                             if (MIS) seg_o = ro;
                             ro = p;
                             st = LIGHT ? EV_WRITE : EV_SCATTER;  // (LIGHT: den = +0 makes `real` false)
+                        }
+                        else if (EXITC && den == 0.0f)
+                        {
+                            terms++;   // exit flights: a null collision in empty space
+                            if (COUNT) zrun++;
                         }
                     }
                 }
@@ -1034,6 +1133,17 @@ ends_done:
             unsigned long long v = c_load;
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0) atomicAdd(&L.counters[12], v);
+        }
+        {
+            // exit flights: tests, hops through the distance field (one byte loaded each), paths ended
+            unsigned long long xv[3] = {c_xtest, c_xout, c_xok};
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+            {
+                unsigned long long v = xv[q];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if (lane == 0) atomicAdd(&L.counters[13 + q], v);
+            }
         }
         // block tallies are wave-uniform: lane 0 adds them
         if (lane == 0)
@@ -1134,6 +1244,47 @@ __global__ __launch_bounds__(256) void danger_k(SceneDev S, unsigned char* out)
         }
     }
     out[idx] = (unsigned char)((any ? 1 : 0) | (self ? 2 : 0));
+}
+// ---- the direction table of the exit flights (render_k).  Three byte planes, one per DOMINANT axis A of a direction in cell
+// units (|e_A| >= |e_B|, |e_C| with e = d * N / extent; (B, C) = the other two axes in increasing order); in plane A bit
+// (e_A > 0) | (e_B > 0) << 1 | (e_C > 0) << 2 of cell c says: every cell a ray from ANY point of cell c with a direction of that class
+// can meet is unmarked, i.e. has no non-empty cell in its 3x3x3 neighbourhood (danger_k bit 0).  Which cells those are: while such
+// a ray advances by delta along A it advances by at most delta along B and C, and it starts less than one cell from the low corner
+// of c: when its A index has advanced by m (delta < m + 1) its B and C indices have advanced by 0..m+1 -- a quarter pyramid of
+// cells.  That set is the slab m = 0 (2 x 2 cells) and the sets of the four cells (A+1, B+{0,1}, C+{0,1}): a recurrence from slice to
+// slice along A, one small kernel per slice (exit_dir_slice_k), from the far end of the grid for the classes that look up the axis
+// and from the near end for the others.  Indices beyond the grid clamp, as the integrator's do.  An octant box (the first form
+// of this table, profiles/experiments/r04_exit_octants.txt) holds three such pyramids and the rest of the octant besides: it sends a
+// path on only once the WHOLE octant is clear, ~110 steps later on average on BASELINE config 2.
+__global__ __launch_bounds__(256) void exit_dir_slice_k(const unsigned char* danger, unsigned char* plane, int nx, int ny, int nz, int axis, int a, int up)
+{
+    // one thread per cell (b, c) of slice `a` of `axis`; the four classes (sB, sC) of direction sA = up
+    const int n[3]  = {nx, ny, nz};
+    const int B     = axis == 0 ? 1 : 0, C = axis == 2 ? 1 : 2;
+    const int nb    = n[B], nc = n[C], na = n[axis];
+    const int t     = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb * nc) return;
+    const int b = t % nb, c = t / nb;
+    const size_t st[3] = {1, (size_t)nx, (size_t)nx * ny};
+    auto at = [&](int ia, int ib, int ic) -> size_t {
+        ib = min(max(ib, 0), nb - 1); ic = min(max(ic, 0), nc - 1);
+        return (size_t)ia * st[axis] + (size_t)ib * st[B] + (size_t)ic * st[C];
+    };
+    const int  an   = up ? a + 1 : a - 1;           // the slice the recurrence reads
+    const bool more = an >= 0 && an < na;
+    unsigned   bits = 0;
+    for (int q = 0; q < 4; q++)
+    {
+        const int sb = (q & 1) ? 1 : -1, sc = (q & 2) ? 1 : -1;
+        const unsigned bit = (up ? 1u : 0u) | ((q & 1) ? 2u : 0u) | ((q & 2) ? 4u : 0u);
+        bool ok = !((danger[at(a, b, c)] | danger[at(a, b + sb, c)] | danger[at(a, b, c + sc)] | danger[at(a, b + sb, c + sc)]) & 1);
+        if (ok && more)
+            ok = ((plane[at(an, b, c)] & plane[at(an, b + sb, c)] & plane[at(an, b, c + sc)] & plane[at(an, b + sb, c + sc)]) >> bit) & 1u;
+        bits |= ok ? (1u << bit) : 0u;
+    }
+    unsigned char* out = plane + at(a, b, c);
+    const unsigned mine = up ? 0xaau : 0x55u;       // the classes of this direction: bit 0 = sA
+    *out = (unsigned char)((*out & ~mine) | bits);
 }
 // ---- where a sun shadow ray has nothing left to meet (counter-based streams; render_k start_shadow).
 // Per NON-EMPTY cell c (a collision needs a positive density, i.e. a non-empty cell; the others are marked 0xffff = unknown): the
@@ -2153,6 +2304,19 @@ void launch_danger(const SceneDev& S, bool quant, unsigned char* out, hipStream_
     dim3   g((unsigned)((n + 255) / 256));
     if (quant) hipLaunchKernelGGL(danger_k<true>, g, dim3(256), 0, st, S, out);
     else hipLaunchKernelGGL(danger_k<false>, g, dim3(256), 0, st, S, out);
+}
+void launch_exit_table(const unsigned char* danger, unsigned char* planes, int nx, int ny, int nz, hipStream_t st)
+{
+    const size_t n = (size_t)nx * ny * nz;
+    const int    dims[3] = {nx, ny, nz};
+    for (int axis = 0; axis < 3; axis++)
+    {
+        unsigned char* plane = planes + (size_t)axis * n;
+        const int      na = dims[axis], cells = (int)(n / (size_t)na);
+        const dim3     g((unsigned)((cells + 255) / 256));
+        for (int a = na - 1; a >= 0; a--) hipLaunchKernelGGL(exit_dir_slice_k, g, dim3(256), 0, st, danger, plane, nx, ny, nz, axis, a, 1);
+        for (int a = 0; a < na; a++) hipLaunchKernelGGL(exit_dir_slice_k, g, dim3(256), 0, st, danger, plane, nx, ny, nz, axis, a, 0);
+    }
 }
 float sun_clip_step(const SceneDev& S)
 {

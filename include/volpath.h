@@ -224,6 +224,13 @@ int vp_get_pixel_table(const Param* p, float* dst, size_t count);
  * dst[cell] (x fastest, count >= nx*ny*nz) = that distance from anywhere in the cell, in units of *step (world units), or
  * 0xffff = unknown (the ray is walked to its end).  Test hook for the certificate; VP_NO_SUN_CLIP=1 switches the table off. */
 int vp_get_sun_clip_table(unsigned short* dst, size_t count, float* step);
+/* Exit flights (any stream): a path in empty space that can meet empty cells only on its way out of the box, and whose null
+ * collisions leave its throughput bit for bit as it is, ends with the environment whatever it draws, and is ended at once instead of
+ * walking there.  The certificate for the cells: dst[A * nx*ny*nz + cell] (x fastest within a plane, count >= 3*nx*ny*nz), A = the
+ * dominant axis of a direction in cell units (d * N / box extent), bit (e_A > 0) | (e_B > 0) << 1 | (e_C > 0) << 2 with (B, C) the
+ * other two axes in increasing order: every cell a ray from anywhere in `cell` with a direction of that class can meet is empty and
+ * has empty neighbours.  Test hook for the certificate; VP_NO_EXIT=1 switches the table off. */
+int vp_get_exit_table(unsigned char* dst, size_t count);
 /* dst[n] = throughput of an unscattered path of the global-majorant estimator after n null collisions in empty space, n < count
  * (spectral tracking: the weight of such a collision is 1 only up to rounding; the light kernel looks the product up by n).
  * Test hook: the sequence is three float32 operations per step and can be restated anywhere. */

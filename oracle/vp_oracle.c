@@ -1402,13 +1402,35 @@ void vpo_render_frame(const vpo_scene* S, const vpo_param* P, int frame, float* 
 
 /* -------------------------------------------- A10: _precompute_opacity -- */
 /* intersect_box kernel.cu:453-481 (tnear clamped at 0 inside) and _precompute_opacity :483-524 */
-void vpo_precompute_opacity(const vpo_scene* S, const float light_dir[3], float* out, int threads)
+/* one voxel of the table: the march from the voxel centre (i, j, k) toward the light, kernel.cu:497-523 */
+float vpo_opacity_voxel(const vpo_scene* S, const float light_dir[3], int i, int j, int k)
 {
-    int nx = S->nx, ny = S->ny, nz = S->nz;
     f3  bmin = mk3(S->box_min[0], S->box_min[1], S->box_min[2]);
     f3  bmax = mk3(S->box_max[0], S->box_max[1], S->box_max[2]);
     f3  ext  = sub3(bmax, bmin);
     f3  d    = mk3(light_dir[0], light_dir[1], light_dir[2]);
+    const float dt = 0.001f;
+    /* normalized_coord :164-167, to_world :171 */
+    f3 s0 = mk3(((float)i + 0.5f) / (float)S->nx, ((float)j + 0.5f) / (float)S->ny, ((float)k + 0.5f) / (float)S->nz);
+    f3 start = add3(mul3(s0, ext), bmin);
+    float tn, tf;
+    int   hit = intersect_box(start, d, bmin, bmax, &tn, &tf);
+    if (tn <= 0.0f) tn = 0.0f;
+    float opacity = 0.0f;
+    if (hit)
+    {
+        for (float t = tn; t < tf; t += dt)
+        {
+            f3 pos = add3(start, muls(d, t));
+            opacity += sample_volume(S, S->grid_u8, S->grid_f32, S->linear, pos);
+        }
+        opacity *= dt;
+    }
+    return opacity;
+}
+void vpo_precompute_opacity(const vpo_scene* S, const float light_dir[3], float* out, int threads)
+{
+    int nx = S->nx, ny = S->ny, nz = S->nz;
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
 #else
@@ -1418,26 +1440,18 @@ void vpo_precompute_opacity(const vpo_scene* S, const float light_dir[3], float*
     for (int k = 0; k < nz; k++)
         for (int j = 0; j < ny; j++)
             for (int i = 0; i < nx; i++)
-            {
-                const float dt = 0.001f;
-                /* normalized_coord :164-167, to_world :171 */
-                f3 s0 = mk3(((float)i + 0.5f) / (float)nx, ((float)j + 0.5f) / (float)ny, ((float)k + 0.5f) / (float)nz);
-                f3 start = add3(mul3(s0, ext), bmin);
-                float tn, tf;
-                int   hit = intersect_box(start, d, bmin, bmax, &tn, &tf);
-                if (tn <= 0.0f) tn = 0.0f;
-                float opacity = 0.0f;
-                if (hit)
-                {
-                    for (float t = tn; t < tf; t += dt)
-                    {
-                        f3 pos = add3(start, muls(d, t));
-                        opacity += sample_volume(S, S->grid_u8, S->grid_f32, S->linear, pos);
-                    }
-                    opacity *= dt;
-                }
-                out[(size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * (size_t)k)] = opacity;
-            }
+                out[(size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * (size_t)k)] = vpo_opacity_voxel(S, light_dir, i, j, k);
+}
+/* a list of voxels (full-size tables are an N^4 march: tests sample them), ijk = n x (i, j, k) */
+void vpo_opacity_voxels(const vpo_scene* S, const float light_dir[3], const int* ijk, int n, float* out, int threads)
+{
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+    for (int q = 0; q < n; q++) out[q] = vpo_opacity_voxel(S, light_dir, ijk[3 * q], ijk[3 * q + 1], ijk[3 * q + 2]);
 }
 
 /* ---------------------------------------------------- A11: scale / gamma -- */

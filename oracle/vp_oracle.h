@@ -106,6 +106,9 @@ int      vpo_bound_radius(int nx, float search_radius);
 void     vpo_bounds_u8(const uint8_t* grid, int nx, int ny, int nz, int radius, int brick, uint8_t* out);
 void     vpo_bounds_f32(const float* grid, int nx, int ny, int nz, int radius, int brick, float* out);
 void     vpo_precompute_opacity(const vpo_scene* S, const float light_dir[3], float* out, int threads);
+/* single voxels of that table (kernel.cu:497-523): what tests compare full-size GPU tables with */
+float    vpo_opacity_voxel(const vpo_scene* S, const float light_dir[3], int i, int j, int k);
+void     vpo_opacity_voxels(const vpo_scene* S, const float light_dir[3], const int* ijk, int n, float* out, int threads);
 float    vpo_sample_density(const vpo_scene* S, const float pos[3]);
 void     vpo_sample_bound(const vpo_scene* S, const float pos[3], float out_max_min[2]);
 float    vpo_sample_opacity(const vpo_scene* S, const float pos[3]);

@@ -196,6 +196,16 @@ class OracleScene:
         S.opacity = _p(self.opacity).value
         return self.opacity
 
+    def opacity_voxels(self, ijk, light_dir=None, threads=0):
+        """single voxels of the optical-depth table (the march of kernel.cu:497-523 per voxel), ijk = (n, 3) ints (i, j, k);
+        light_dir: the direction handed to precompute_opacity (default: the scene's sun, as host.cpp:341 does)"""
+        threads = threads or DEFAULT_THREADS
+        ijk = np.ascontiguousarray(ijk, np.int32)
+        out = np.empty(len(ijk), np.float32)
+        d = self.S.sun_dir if light_dir is None else (C.c_float * 3)(*[float(v) for v in light_dir])
+        lib().vpo_opacity_voxels(C.byref(self.S), d, _p(ijk), len(ijk), _p(out), threads)
+        return out
+
     def render_frame(self, P, frame, accum=None, rows=None, threads=0):
         threads = threads or DEFAULT_THREADS
         if accum is None:

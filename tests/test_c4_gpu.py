@@ -606,6 +606,8 @@ def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
         # the camera rays' walk ahead of the integrator (approach_k / approach_local_k): off, cut short after a few steps / segments
         dict(VP_NO_APPROACH="1"), dict(VP_NO_APPROACH_LOCAL="1"), dict(VP_APPROACH_STEPS="3"), dict(VP_APPROACH_STEPS="0"),
         dict(VP_APPROACH_STEPS="40", VP_NO_LDS_HELPER="1"), dict(VP_APPROACH_FRAMES_LOG2="0"), dict(VP_APPROACH_FRAMES_LOG2="1"),
+        # exit flights (paths that can only leave the box are ended at once): off, tested at once, tested late
+        dict(VP_NO_EXIT="1"), dict(VP_EXIT_K="1"), dict(VP_EXIT_K="40"),
     ]
     for env_set in settings:
         saved = {k: os.environ.get(k) for k in env_set}
@@ -629,6 +631,53 @@ def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
     assert np.array_equal(render(), want)
 
 
+@pytest.mark.parametrize("workload", ["c3", "c4s", "c4f"])
+def test_full_size_opacity_tables_match_the_oracle_on_sampled_voxels(vp, oracle, workload):
+    """precompute_opacity (A10, kernel.cu:483-553) AT FULL SIZE: the optical-depth table the GPU builds for the 256^3 and 512^3 bench
+    volumes against the oracle's march of the same voxel (vpo_opacity_voxel), tolerance 0, on 4096 + 56 voxels per light direction
+    -- random ones, the eight corners, and voxels on every face -- for the default sun and for two more directions, so that the
+    marches leave the box through each of its six faces.  (The whole table is compared at 32^3 and the fuzz sizes; the oracle's
+    whole-table precompute is an N^4 march.)  This is what closes the loop of
+    test_full_size_workloads_match_the_oracle_on_sampled_pixels, whose oracle reads the GPU-built table from frame 11 on."""
+    from volpath import scene as vscene
+    cfg = vscene.WORKLOADS[workload]
+    n = cfg["n"]
+    P, info = vscene.setup(workload, rng_mode=2, last_frame=0)
+    env, sun_dir, sun_power = info["sunsky"]
+    grid = vscene.host_volume(workload)
+    osc = oracle.OracleScene(grid, env, sun_dir, sun_power, brick=cfg["brick"], estimator=cfg["est"], rng_mode=2,
+                             seed=(0x9E3779B9, 0x85EBCA6B), inv_view=vscene.camera_of(cfg))
+    rng = np.random.default_rng(11)
+    ijk = [rng.integers(0, n, size=(4096, 3))]
+    ijk.append(np.array([[a, b, c] for a in (0, n - 1) for b in (0, n - 1) for c in (0, n - 1)]))
+    for axis in range(3):                      # eight voxels on each of the six faces
+        for side in (0, n - 1):
+            f = rng.integers(0, n, size=(8, 3))
+            f[:, axis] = side
+            ijk.append(f)
+    ijk = np.concatenate(ijk).astype(np.int32)
+    exits = set()
+    for d in (sun_dir, (0.6, -0.5, 0.62), (-0.7, 0.1, 0.7)):
+        d = np.asarray(d, np.float32)
+        d = tuple(float(v) for v in d / np.float32(np.sqrt(np.float32((d * d).sum()))))
+        vp.precompute_opacity(d)
+        table = vp.opacity_table((n, n, n))                      # [k][j][i]
+        got = table[ijk[:, 2], ijk[:, 1], ijk[:, 0]]
+        want = osc.opacity_voxels(ijk, light_dir=d)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, f"{len(bad)} of {len(ijk)} voxels differ toward {d}: first {ijk[bad[0]]} {got[bad[0]]} vs {want[bad[0]]}"
+        assert (want > 0).mean() > 0.02          # the marches meet the medium
+        # through which face the marches leave (float64 slab test from the voxel centres)
+        c = ((ijk + 0.5) / n) * 2.0 - 1.0
+        with np.errstate(divide="ignore"):
+            t = np.where(np.array(d) > 0, (1.0 - c) / np.array(d, np.float64), (-1.0 - c) / np.array(d, np.float64))
+        t = np.where(np.array(d) == 0, np.inf, t)
+        ax = t.argmin(1)
+        exits |= {(int(a), bool(d[a] > 0)) for a in ax}
+    assert len(exits) == 6, exits
+    vp.precompute_opacity(sun_dir)
+
+
 @pytest.mark.parametrize("workload,first,rng_mode", [("c2", 0, 2), ("c3", 0, 2), ("c4s", 0, 2), ("c4f", 0, 2), ("c3", 9, 2), ("c4f", 9, 2),
                                                      ("c3ref", 0, 0), ("c3ref", 9, 0), ("c2", 0, 0)])
 def test_full_size_workloads_match_the_oracle_on_sampled_pixels(vp, oracle, workload, first, rng_mode):
@@ -638,7 +687,8 @@ def test_full_size_workloads_match_the_oracle_on_sampled_pixels(vp, oracle, work
     ray meets empty cells only and 300 that miss the box, four frames, tolerance 0.  (The whole-image comparisons stop at 120x56
     and 64^3; the oracle takes a quarter of an hour per full-size frame.)  first = 9: frames 9..12, across the live kernel's
     switch to the optical-depth table at frame 11 (quirk Q5); the oracle's N^4 precompute of that table is not affordable at these
-    sizes, so it reads the table the GPU built -- itself compared with the oracle's at 32^3 in test_parity_gpu.py.
+    sizes, so it reads the table the GPU built -- itself compared with the oracle's march voxel by voxel on 4152 sampled voxels per
+    light direction at these very sizes (test_full_size_opacity_tables_match_the_oracle_on_sampled_voxels) and whole at 32^3.
     rng_mode 0: the reference's own sampler.h streams, on c3ref = the reference's live configuration (its estimator, its per-voxel
     bound table, its default scene and window-independent camera) -- what a run of the reference itself computes, sample by sample."""
     import ctypes as C

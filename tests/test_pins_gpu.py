@@ -521,6 +521,67 @@ def test_sun_clip_certificate_holds_in_float64(vp, sun, kind):
     assert (table[cell_nonempty] * step).mean() < 0.5 * np.linalg.norm(bmax - bmin)
 
 
+@pytest.mark.parametrize("kind", ["julia", "ragged"])
+def test_exit_table_certificates_hold_in_float64(vp, kind):
+    """Exit flights (vp_kernels.hip render_k / exit_dir_slice_k): a path that can meet empty cells only on its way out of the box is
+    ended at once.  The table that says so is a claim about geometry, checked here in float64 against the raw volume, without the
+    oracle: for random cells and random directions whose class bit is set, from a random start point in the cell, every point of the
+    ray up to the box exit lies in a cell whose 2x2x2 texels are all zero.  Also: the table is not vacuous (most empty cells far
+    from matter certify most directions) and never certifies a direction out of a non-empty cell.
+    `ragged`: a non-cubic grid in an off-centre, non-cubic box (the dominant axis is that of the direction in CELL units)."""
+    import scenes
+    rng = np.random.default_rng(23)
+    if kind == "julia":
+        grid = vp.julia_volume(48)
+        bmin, bmax = np.array([-1.0, -1.0, -1.0]), np.array([1.0, 1.0, 1.0])
+        vp.init_volume(grid, brick=1, linear=True)
+    else:
+        g = scenes.blob_volume_u8(28, seed=5)[:20, :, :]
+        grid = np.ascontiguousarray(np.pad(g, ((0, 0), (0, 0), (0, 8)))[:, :28, :36])      # nz, ny, nx = 20, 28, 36
+        bmin, bmax = np.array([-0.7, -1.3, 0.1]), np.array([1.6, 0.2, 1.4])
+        vp.init_volume(grid, box=(tuple(bmin), tuple(bmax)), brick=1, linear=True)
+    nz, ny, nx = grid.shape
+    N = np.array([nx, ny, nz], np.float64)
+    table = vp.exit_table((nz, ny, nx))
+    g = np.pad(grid, ((0, 1), (0, 1), (0, 1)), mode="edge") != 0
+    cell_nonempty = np.zeros((nz, ny, nx), bool)
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                cell_nonempty |= g[dz:dz + nz, dy:dy + ny, dx:dx + nx]
+    assert not table[:, cell_nonempty].any()                      # no direction is certified out of a non-empty cell
+    cell_edges = (bmax - bmin) / N
+    checked = rays = 0
+    for _ in range(4000):
+        c = np.array([rng.integers(0, nx), rng.integers(0, ny), rng.integers(0, nz)])
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        e = d * N / (bmax - bmin)                                 # the direction in cell units
+        ae = np.abs(e)
+        A = 0 if (ae[0] >= ae[1] and ae[0] >= ae[2]) else (1 if ae[1] >= ae[2] else 2)
+        B, Cx = [a for a in range(3) if a != A]
+        cls = int(e[A] > 0) | int(e[B] > 0) << 1 | int(e[Cx] > 0) << 2
+        if not (table[A, c[2], c[1], c[0]] >> cls) & 1:
+            continue
+        lo = np.where(c == 0, -0.5, c.astype(np.float64))
+        hi = np.where(c == N - 1, N - 0.5, c + 1.0)
+        xb = lo + (hi - lo) * rng.random(3)
+        p0 = bmin + (xb + 0.5) / N * (bmax - bmin)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tt = np.where(d > 0, (bmax - p0) / d, np.where(d < 0, (bmin - p0) / d, np.inf))
+        t1 = float(tt.min())
+        ts = np.arange(0.0, max(t1, 0.0) + cell_edges.min() / 20, cell_edges.min() / 20)
+        q = ((p0 + d * ts[:, None]) - bmin) / (bmax - bmin) * N - 0.5
+        idx = np.clip(np.floor(np.maximum(q, 0)).astype(int), 0, (N - 1).astype(int))
+        assert not cell_nonempty[idx[:, 2], idx[:, 1], idx[:, 0]].any(), (c, d)
+        checked += len(ts)
+        rays += 1
+    assert rays > 800 and checked > 100000
+    # not vacuous: cells on the faces of the box certify the directions that leave through their face at once
+    assert (table[0, :, :, nx - 1] & 0xaa).any() and (table[0, :, :, 0] & 0x55).any()
+    assert (table != 0).mean() > 0.3
+
+
 def test_shadow_rays_draw_from_their_own_substream(vp):
     """Counter-based streams: what a path draws after a light estimate does not depend on the shadow ray.  With the sun's power
     at zero the image is the environment seen by the escaping paths, so two sun directions (shadow rays of different lengths,
