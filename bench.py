@@ -4,7 +4,7 @@
   python bench.py --gpus N --steps K --warmup W
 
 runs as typed for any N: with N > 1 and no WORLD_SIZE in the environment it starts
-`python -m torch.distributed.run --standalone --nproc-per-node N bench.py ...` as a CHILD process (before anything
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...` as a CHILD process (before anything
 touches the GPU) and relays its JSON line and exit code; under an external torch.distributed.run it is one rank.
 
 A step = one complete render job of the Julia-256^3 scene at 800x600: `spp` samples per pixel, pixel tiles dealt over
@@ -12,8 +12,11 @@ the ranks (vp_tile_owner), followed (N > 1) by one RCCL reduce of the HDR accumu
 (default): spp = 1024 * N, every GPU integrates 800*600*1024 samples per step; at N = 1 this is BASELINE.json's
 configs[1] exactly.  --scaling strong: spp = 1024 whatever N (the job is fixed, the ranks share it); --scaling both
 prints the weak line with the strong measurement inside it ("strong").  Inputs are resident in HBM before the timed
-region.  Prints ONE JSON line on rank 0; at N = 1 it also carries the reference's live estimator on the same scene
-(BASELINE configs[2], "secondary") and the CPU baseline.
+region.  Prints ONE JSON line on rank 0; at N = 1 it also carries, under "secondary", the workloads that do physics in
+every pixel or on the reference's own streams -- each with its own roofline and CPU baseline, all inside the one run the
+driver times: BASELINE configs[2] (c3), the reference's live configuration on its own sampler.h streams (c3ref_samplerh),
+and the two flagged stand-ins of configs[3] (c4s; c4f, the frame-filling cloud, at that config's 4096 spp) -- and the
+headline's own general class (the 12 % of its pixels that scatter) as "general_class_msamples_per_s".
 """
 import argparse
 import json
@@ -35,6 +38,14 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
 # workload that does more (C2's global majorant: ~525 lookups) or less work per sample is not mis-read as bandwidth.
 REFERENCE_ESTIMATOR_BYTES_PER_SAMPLE = 8 * 97.6 + 2 * 51.3 + 16 * 1.0 + 32
 WORKLOAD_CHOICES = ["c2", "c3", "c3ref", "c1", "c4s", "c4f"]
+RNG_NAMES = {"philox": "philox2x32-10", "philox7": "philox2x32-7", "samplerh": "sampler.h"}
+# what the default N = 1 line carries besides the headline: (key, workload, stream, spp per step, timed steps, CPU seconds)
+SECONDARY = [
+    ("c3", "c3", "philox7", 1024, 3, 5.0),                  # BASELINE configs[2]
+    ("c3ref_samplerh", "c3ref", "samplerh", 1024, 3, 5.0),  # the reference's live configuration on its own streams (host.cpp:631)
+    ("c4s", "c4s", "philox7", 1024, 1, 5.0),                # configs[3] shape, Julia stand-in
+    ("c4f", "c4f", "philox7", 4096, 1, 6.0),                # configs[3] shape and spp, frame-filling cloud stand-in
+]
 
 
 def bytes_per_sample(c, loads):
@@ -60,17 +71,21 @@ def effective_cores():
     return max(1, n)
 
 
-def cpu_baseline(workload, seconds_hint=15.0):
-    """The oracle (CPU restatement, 'port') on this host's cores, on a bounded sample of the same workload."""
+def cpu_baseline(workload, seconds_hint=15.0, rng="philox7", grid=None):
+    """The oracle (CPU restatement, 'port') on this host's cores, on a bounded sample of the same workload.
+    grid: the workload's uchar volume if the caller holds it already (the GPU leg's: the two voxelisers are tested bit for bit
+    against each other); else the oracle voxelises it itself."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from volpath import scene as vscene
     cfg = vscene.WORKLOADS[workload]
     O.build()
-    grid = vscene.host_volume(workload, oracle=O)
+    if grid is None:
+        grid = vscene.host_volume(workload, oracle=O)
     env, sun_dir, sun_power = vscene.default_sunsky()
+    orng = {"philox": O.RNG_PHILOX, "philox7": O.RNG_PHILOX7, "samplerh": O.RNG_SAMPLERH}[rng]
     osc = O.OracleScene(grid, env, sun_dir, sun_power,
-                        brick=cfg["brick"], estimator=cfg["est"], rng_mode=O.RNG_PHILOX7, seed=(0x9E3779B9, 0x85EBCA6B),
+                        brick=cfg["brick"], estimator=cfg["est"], rng_mode=orng, seed=(0x9E3779B9, 0x85EBCA6B),
                         inv_view=vscene.camera_of(cfg))
     P = O.default_param(cfg["width"], cfg["height"])
     if cfg["chromatic"]:
@@ -93,7 +108,7 @@ def cpu_baseline(workload, seconds_hint=15.0):
     dt = time.time() - t0
     return {"value": tot / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"frames 0..{nframes - 1} of {cfg['width']}x{cfg['height']} ({tot} samples, {dt:.1f} s, "
-                      f"OpenMP over rows, Philox2x32-7 streams"
+                      f"OpenMP over rows, {RNG_NAMES[rng]} streams"
                       + ("; frames 11+ would read the optical-depth table, whose CPU precompute is not affordable here)"
                          if cfg["est"] == O.EST_DECOMP and not across_q5 else ")")}
 
@@ -101,7 +116,11 @@ def cpu_baseline(workload, seconds_hint=15.0):
 def self_launch(args, argv):
     """`python bench.py --gpus N` typed by hand (no WORLD_SIZE): start the ranks as a child torchrun.  Nothing in this process
     has touched the GPU yet, and it never will: it relays the child's output and exit code."""
-    port = 29500 + (os.getpid() % 2000)
+    # a port nobody holds right now: bound to port 0 here, released, handed to the launcher (ADVICE r3: no pid arithmetic)
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
@@ -111,19 +130,25 @@ def self_launch(args, argv):
     raise SystemExit(p.returncode)
 
 
-def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=True):
-    """Time `steps` render jobs of one workload; returns the fields of the JSON line (rank 0) or None."""
+def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=True, rng=None, warmup_spp=None, count_frames=None):
+    """Time `steps` render jobs of one workload; returns the fields of the JSON line (rank 0) or None.
+    rng: the stream (default args.rng); warmup_spp: samples per pixel of a warm-up step (default: as a timed step)."""
     import torch
     import torch.distributed as dist
     import volpath as vp
     from volpath import scene as vscene
     rank, world, dev, stream, rehearsal = ctx["rank"], ctx["world"], ctx["dev"], ctx["stream"], ctx["rehearsal"]
+    rng = rng or args.rng
     spp_step = spp_per_gpu * world if scaling == "weak" else spp_per_gpu
-    total_steps = warmup + steps
-    rng_mode = {"philox": vp.RNG_PHILOX, "philox7": vp.RNG_PHILOX7, "samplerh": vp.RNG_SAMPLERH}[args.rng]
-    count_frames = 4 if vscene.WORKLOADS[workload]["est"] == vp.EST_GLOBAL else 16  # frames of the (untimed) work-counter pass
+    warmup_spp = spp_step if warmup_spp is None else warmup_spp
+    rng_mode = {"philox": vp.RNG_PHILOX, "philox7": vp.RNG_PHILOX7, "samplerh": vp.RNG_SAMPLERH}[rng]
+    cfg = vscene.WORKLOADS[workload]
+    if count_frames is None:   # frames of the (untimed) work-counter pass
+        count_frames = 4 if (cfg["est"] == vp.EST_GLOBAL or cfg["n"] > 256) else 8
+    # the live kernel reads the optical-depth table from frame 11 on (quirk Q5): a job of hundreds of frames is counted there
+    count_first = 16 if (cfg["est"] == vp.EST_DECOMP and spp_step * steps >= 64) else 0
     P, info = vscene.setup(workload, rng_mode=rng_mode, rank=rank, world=world,
-                           last_frame=max(spp_step * total_steps, count_frames), sunsky=ctx.setdefault("sunsky", None))
+                           last_frame=max(warmup_spp * warmup + spp_step * steps, count_first + count_frames), sunsky=ctx.setdefault("sunsky", None))
     ctx["sunsky"] = info["sunsky"]
     W, H = P.width, P.height
 
@@ -149,16 +174,16 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
         vp.prepare(P)
         per_camera_setup_ms = (time.perf_counter() - t0) * 1e3
 
-        # work counters (untimed, counting kernel variant): per-sample lookups of THIS build
+        # work counters (untimed, counting kernel variant), per pixel class: per-sample lookups of THIS build
         vp.enable_counters(True)
         vp.read_counters(reset=True)
-        vp.render_frames(acc.data_ptr(), 0, count_frames, P)
+        vp.render_frames(acc.data_ptr(), count_first, count_frames, P)
         counters = vp.read_counters(reset=True)
         vp.enable_counters(False)
 
-        def step(i):
+        def step(first, spp):
             acc.zero_()
-            vp.render_frames(acc.data_ptr(), i * spp_step, spp_step, P)
+            vp.render_frames(acc.data_ptr(), first, spp, P)
             if world > 1 and rehearsal:
                 host = acc.cpu()
                 dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
@@ -169,17 +194,18 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
                 image.add_(acc)
 
         for i in range(warmup):
-            step(i)
+            step(i * warmup_spp, warmup_spp)
         barrier()
         vp.render_time_ms(reset=True)
         vp.render_class_time_ms(reset=True)
         t0 = time.perf_counter()
-        for i in range(warmup, total_steps):
-            step(i)
+        for i in range(steps):
+            step(warmup * warmup_spp + i * spp_step, spp_step)
         barrier()
         dt = time.perf_counter() - t0
         kern_ms, launches = vp.render_time_ms(reset=True)
         class_ms, class_px = vp.render_class_time_ms(reset=True)
+        light_const_flag = vp.last_light_const()
 
     kern_ms, launches = max(kern_ms, 1e-9), max(launches, 1)
     # per-rank diagnostics: wall time of the timed region and kernel time of each rank (rank order), so that an N > 1 line
@@ -201,9 +227,33 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
     value = samples_total / dt / 1e6
     launch_ms = kern_ms / launches
     n_cnt = max(counters["samples"], 1)
-    loaded_bps = bytes_per_sample(counters, loads=True)
+    # Bytes the TIMED kernels move (SURVEY section 8d formula on the build's own counters, class by class -- ADVICE r3): the general
+    # class by the counters (8 B per density lookup that issued a load, 2 B per bound lookup, 32 B per optical-depth lookup, 16 B
+    # per environment lookup, 32 B of accumulator traffic per sample: a 16-byte staging write, read once by the reduce); a class
+    # that is a per-pixel constant (the box-missing pixels always; the light class where a null collision in empty space leaves a
+    # throughput of 1 as it is) costs ONE environment lookup per pixel and launch and the 32 B per sample of the staging slot; a
+    # light class that is integrated (its kernel beside the general one) fetches no cells: bound lookups + one environment lookup.
+    # The counting pass walks every light path, so its env / bound counts are split by the classes' sample shares.
+    light_const = class_px["light"] > 0 and light_const_flag
+    cper = {k: counters[k] / n_cnt for k in ("density_lookups", "density_loads", "bound_lookups", "opacity_lookups", "env_lookups", "scatters")}
+    smp_g = float(class_px["general"]) * frames_rank
+    smp_l = float(class_px["light"]) * frames_rank
+    smp_m = float(class_px["misses_box"]) * frames_rank
+    # per general sample: every load, optical-depth lookup and scatter is the general class's; bound / environment lookups of the
+    # counting pass are spread over all samples that make them
+    bound_other = 1.0 if cfg["est"] != vp.EST_GLOBAL else 0.0          # a box-missing sample of a local estimator: one bound fetch
+    bytes_gen = (8.0 * cper["density_loads"] + 32.0 * cper["opacity_lookups"]) * samples_rank \
+        + (2.0 * max(cper["bound_lookups"] * samples_rank - bound_other * smp_m, 0.0) * (smp_g / max(smp_g + smp_l, 1.0))) \
+        + (16.0 + 32.0) * smp_g
+    if light_const:
+        bytes_light = 16.0 * class_px["light"] * launches + 32.0 * smp_l
+    else:
+        bytes_light = 2.0 * max(cper["bound_lookups"] * samples_rank - bound_other * smp_m, 0.0) * (smp_l / max(smp_g + smp_l, 1.0)) + (16.0 + 32.0) * smp_l
+    bytes_miss = 16.0 * class_px["misses_box"] * launches + 32.0 * smp_m
+    loaded_total = bytes_gen + bytes_light + bytes_miss
+    loaded_bps = loaded_total / max(samples_rank, 1.0)
     estimator_bps = bytes_per_sample(counters, loads=False)
-    achieved = loaded_bps * samples_rank / launches / (launch_ms * 1e-3) / 1e9
+    achieved = loaded_total / launches / (launch_ms * 1e-3) / 1e9
     # per pixel class: which kernel integrates how many samples at what rate (the general and the light kernel run side by
     # side, so their times overlap; each is measured with its own pair of HIP events)
     per_class = {}
@@ -212,13 +262,15 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
         smp = float(px) * frames_rank
         per_class[name] = {"pixels": px, "pixel_fraction": px / max(pixels_rank, 1), "samples": smp, "kernel_ms": ms,
                            "kernel_ms_per_launch": ms / launches, "msamples_per_s": (smp / (ms * 1e-3) / 1e6) if ms > 0 else None}
+    per_class["light"]["per_pixel_constant"] = bool(light_const)
     # the density lookups of the light and box-missing classes issue no load; every load belongs to the general kernel
     gen = per_class["general"]
     if gen["kernel_ms"] > 0:
         lookups_general = counters["density_lookups"] / n_cnt * samples_rank
-        # (estimator lookups of the general pixels are not counted separately; loads are all theirs)
         gen["density_loads_per_s"] = counters["density_loads"] / n_cnt * samples_rank / (gen["kernel_ms"] * 1e-3)
         gen["density_loads_per_sample"] = counters["density_loads"] / n_cnt * samples_rank / max(gen["samples"], 1.0)
+        gen["loaded_bytes_per_sample"] = bytes_gen / max(smp_g, 1.0)
+        gen["loaded_GBps"] = bytes_gen / (gen["kernel_ms"] * 1e-3) / 1e9
         per_class["all"] = {"density_lookups_per_s": lookups_general / (kern_ms * 1e-3)}
     out = {
         "metric": "Msamples/sec (WxHxspp) + achieved HBM GB/s, Julia 256^3 @ 800x600",
@@ -229,21 +281,27 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
                    "spp_per_step": spp_step, "samples_per_step": int(W * H * spp_step),
                    "estimator": "global_majorant" if info["est"] == vp.EST_GLOBAL else "decomposition",
                    "bound_brick": info["brick"],
-                   "rng": {"philox": "philox2x32-10", "philox7": "philox2x32-7", "samplerh": "sampler.h"}[args.rng],
+                   "rng": RNG_NAMES[rng],
                    "parallelism": f"pixel-tiles x{world}" + (" + RCCL reduce" if world > 1 else ""),
                    "sky": "Hosek sun/sky bake, setup_sunsky(0.5, 0.2), 1024x512"},
+        # the class that does the physics: the pixels whose camera ray can meet the medium (the others are per-pixel constants in
+        # this scene: quirk Q3, no pixel jitter) -- the number to track; `value` is BASELINE's metric, all pixels
+        "general_class_msamples_per_s": gen["msamples_per_s"],
         "per_camera_setup_ms": per_camera_setup_ms,
         "per_class": per_class,
     }
+    if warmup_spp != spp_step:
+        out["config"]["warmup_spp"] = warmup_spp
     if info.get("note"):
         out["config"]["note"] = info["note"]
     if full:
-        # counters of the render kernels from the committed rocprofv3 PMC passes of THIS workload (not measured in this run: PMC
-        # collection serialises kernels); scaled to this run's launch size
-        pmc, traffic, valu_frac, lane_util, pmc_src = {}, None, None, None, None
+        # counters of the render kernels from the committed rocprofv3 PMC passes of THIS workload and stream (not measured in this
+        # run: PMC collection serialises kernels); scaled to this run's launch size
+        pmc, traffic, valu_frac, lane_util, pmc_src, stalls = {}, None, None, None, None, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
+        tkey = workload if rng == "philox7" else f"{workload}_{rng}"
         if os.path.exists(tp):
-            pmc = json.load(open(tp)).get(workload, {})
+            pmc = json.load(open(tp)).get(tkey, {})
         if pmc:
             ref_samples = float(pmc["launch"].split("(")[1].split()[0])
             scale = (float(W) * H * frames_rank / launches) / ref_samples
@@ -251,17 +309,24 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
             if pmc.get("valu_insts_per_launch"):
                 valu_frac = pmc["valu_insts_per_launch"] * scale / (launch_ms * 1e-3) / VALU_ISSUE_PEAK
             lane_util = pmc.get("lane_util")
-            pmc_src = f"{pmc.get('source')} @ {pmc.get('commit')} (rocprofv3 --pmc passes of `bench.py --workload {workload}`; " \
+            stalls = pmc.get("stalls")
+            pmc_src = f"{pmc.get('source')} @ {pmc.get('commit')} (rocprofv3 --pmc passes of `bench.py --workload {workload} --rng {rng}`; " \
                       f"fabric-side counters, Infinity-Cache hits included)"
-        loaded_per_launch = loaded_bps * samples_rank / launches
+        loaded_per_launch = loaded_total / launches
         traffic_gbps = (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None
-        bounded_by = "valu_issue"
-        if traffic_gbps and valu_frac and traffic_gbps / HBM_ACHIEVABLE_GBS > valu_frac:
-            bounded_by = "memory_system (line-granular gathers)"
+        # What bounds the launch, from the committed counters (profiles/r04_stalls.md has the derivation): the kernel issues
+        # valu_issue_frac of the chip's wave-instruction peak (at 2 cycles each; its mix of conversions, compares, 64-bit multiplies
+        # and divide sequences costs ~1.4x that) with lane_util of the lanes active, its waves spend wait_frac of their cycles in
+        # s_waitcnt -- a vector-issue-bound state machine with latency left over, not a memory-bound gather.  The frame-filling
+        # 512^3 cloud alone also sits near what the fabric delivers in 128-byte lines.
+        bounded_by = None
+        if valu_frac is not None:
+            bounded_by = "vector_issue x lane_utilisation (from the committed profile)"
+            if traffic_gbps and traffic_gbps / HBM_ACHIEVABLE_GBS > valu_frac:
+                bounded_by = "memory_system (line-granular gathers) and vector_issue (from the committed profile)"
         out["roofline"] = {
-            # bound/achieved/peak/frac: the contract's HBM roofline on the bytes the timed kernels LOAD (the build's own counters,
-            # SURVEY section 8d).  The kernel is not bound by bytes: vector-instruction issue and lane utilisation bound it
-            # (bounded_by, valu_issue_frac, lane_util); its working set is cache-resident.
+            # bound/achieved/peak/frac: the contract's HBM roofline on the bytes the timed kernels move (the build's own counters,
+            # SURVEY section 8d, class by class).  The kernel is not bound by bytes: its working set is cache-resident; see bounded_by
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": pmc_src,
             "traffic_over_loaded_bytes": (traffic / loaded_per_launch) if traffic else None,
@@ -269,17 +334,19 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
             # as achievable: the frame-filling 512^3 cloud (c4f) sits near it, the Julia workloads far below
             "traffic_GBps": traffic_gbps, "traffic_frac_of_achievable_hbm": (traffic_gbps / HBM_ACHIEVABLE_GBS) if traffic_gbps else None,
             "bounded_by": bounded_by, "valu_issue_frac": valu_frac, "valu_issue_peak_per_s": VALU_ISSUE_PEAK, "lane_util": lane_util,
-            "kernel": "vp::render_k (a launch = the general kernel -- behind vp::approach_k, which walks the camera rays through their "
-                      "certified-empty stretch, where the global-majorant estimator runs on a counter-based stream -- and, where the light "
-                      "pixels are not per-pixel constants, their kernel beside it on a second stream; HIP events from the start of the "
-                      "first to the end of the last; the counters are summed over these kernels)",
+            "stalls": stalls,
+            "kernel": "vp::render_k (a launch = the general kernel -- behind vp::approach_k / approach_local_k, which walk the camera rays "
+                      "through their certified-empty stretch -- and, where the light pixels are not per-pixel constants, their kernel beside "
+                      "it on a second stream; HIP events from the start of the first to the end of the last; the counters are summed over "
+                      "these kernels)",
             "launch_ms": launch_ms, "launches": launches,
             "loaded_bytes_per_sample": loaded_bps,
+            "loaded_bytes_per_general_sample": bytes_gen / max(smp_g, 1.0),
             "estimator_bytes_per_sample": estimator_bps,
             "estimator_equivalent_GBps": estimator_bps * samples_rank / launches / (launch_ms * 1e-3) / 1e9,
             "reference_estimator_bytes_per_sample": REFERENCE_ESTIMATOR_BYTES_PER_SAMPLE,
-            "lookups_per_sample": {k: counters[k] / n_cnt for k in
-                                   ("density_lookups", "density_loads", "bound_lookups", "opacity_lookups", "env_lookups", "scatters")}}
+            "lookups_per_sample": cper,
+            "lookups_counted_on": f"frames {count_first}..{count_first + count_frames - 1} (counting kernel variant, untimed)"}
     else:
         out["loaded_GBps"] = achieved
         out["launch_ms"] = launch_ms
@@ -290,6 +357,7 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
     if rehearsal:
         out["config"]["parallelism"] += " (REHEARSAL: all ranks on one GPU, gloo)"
     out["_image"] = image
+    out["_grid"] = info.get("grid")
     return out
 
 
@@ -309,7 +377,8 @@ def main():
                          "like the others), philox = Philox2x32-10 (the round-1 default, 4-6 %% slower), samplerh = the reference's "
                          "sampler.h streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the second tracked workload (c3) of the N = 1 line")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the N = 1 line")
+    ap.add_argument("--secondary", default=None, help="comma-separated subset of the secondary workloads (c3,c3ref_samplerh,c4s,c4f)")
     ap.add_argument("--dump-image", default=None, help="rank 0 saves the summed HDR image (.npy) -- used by tests")
     args = ap.parse_args()
 
@@ -351,31 +420,47 @@ def main():
     strong = None
     if args.scaling == "both" and world > 1:
         strong = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, "strong", full=False)
-    secondary = None
+    secondary = {}
     if world == 1 and args.workload == "c2" and not args.no_secondary:
-        # the reference's LIVE estimator (decomposition tracking) on the same scene, BASELINE configs[2]: tracked every round
-        # beside the headline.  Its brick table goes through LDS because the config names that; the same estimator reading the
-        # reference's per-voxel table from global memory (workload c3ref) is faster (profiles/).
-        secondary = run_workload("c3", args, ctx, args.spp, min(args.steps, 3), 1, "weak", full=False)
+        # The workloads that do physics in every pixel, or on the reference's own streams, under the same clock as the headline
+        # (VERDICT r3 item 1): BASELINE configs[2] (its brick table goes through LDS because the config names that; the same
+        # estimator on the reference's per-voxel table, c3ref, is as fast), the reference's LIVE configuration on its own sampler.h
+        # streams (what src/volumeRender.cpp:631 computes, sample for sample), and the two flagged stand-ins of configs[3] -- the
+        # frame-filling cloud at that config's 4096 spp.  One warm-up step of 64 spp each: tables, lists and clocks, not 13 s of cloud.
+        only = set(args.secondary.split(",")) if args.secondary else None
+        for key, wl, rng, spp, steps, cpu_s in SECONDARY:
+            if only is not None and key not in only:
+                continue
+            sec = run_workload(wl, args, ctx, spp, min(steps, max(args.steps, 1)), 1, "weak", full=True, rng=rng, warmup_spp=64)
+            sec.pop("_image")
+            grid = sec.pop("_grid")
+            if not args.no_cpu_baseline:
+                sec["cpu_baseline"] = cpu_baseline(wl, seconds_hint=cpu_s, rng=rng, grid=grid)
+            del grid
+            secondary[key] = sec
+        if "c3" in secondary:
+            secondary["c3"]["note"] = ("BASELINE configs[2]: 8^3 bricks staged through LDS as the config asks; the same estimator on the "
+                                       "reference's per-voxel table read from global memory (workload c3ref) is as fast")
+        if "c3ref_samplerh" in secondary:
+            secondary["c3ref_samplerh"]["note"] = ("the reference's live configuration (decomposition tracking, its per-voxel bound table, its "
+                                                   "default scene) on its own sampler.h streams: the parity mode; a sequential stream has no "
+                                                   "shadow-ray sub-streams, so its shadow rays walk to their end")
 
     if rank == 0:
         image = out.pop("_image")
+        grid = out.pop("_grid")
         if strong:
             strong.pop("_image")
+            strong.pop("_grid")
             out["strong"] = {k: strong[k] for k in ("value", "unit", "ms_per_step", "scaling", "per_class", "ranks") if k in strong}
             out["strong"]["spp_per_step"] = strong["config"]["spp_per_step"]
         if secondary:
-            secondary.pop("_image")
-            out["secondary"] = {"c3": {k: secondary[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "per_class",
-                                                                  "per_camera_setup_ms", "loaded_GBps", "launch_ms")}}
-            out["secondary"]["c3"]["note"] = ("BASELINE configs[2]: 8^3 bricks staged through LDS as the config asks; the LDS table is "
-                                              "SLOWER than the same estimator on the reference's per-voxel table read from global memory "
-                                              "(workload c3ref)")
+            out["secondary"] = secondary
         if args.dump_image:
             import numpy as np
             np.save(args.dump_image, image.cpu().numpy())
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            out["cpu_baseline"] = cpu_baseline(args.workload, rng=args.rng, grid=grid)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

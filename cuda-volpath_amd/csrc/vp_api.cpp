@@ -131,6 +131,7 @@ struct State
     unsigned*   d_appr_aux[3] = {nullptr, nullptr, nullptr};   // per render target (caller's stream, two look-ahead slots): LaunchDev::approach_aux
     size_t      appr_aux_bytes[3] = {0, 0, 0};
     int         last_approach = 0;            // vp_last_approach_mode
+    int         last_light_const = 0;         // vp_last_light_const
     bool        use_approach_local = true;    // ... and approach_local_k ahead of the decomposition estimator (VP_NO_APPROACH_LOCAL=1: off)
     bool        use_approach = true;          // approach_k ahead of the global-majorant integrator (VP_NO_APPROACH=1: off)
     unsigned    approach_fshift_max = 6;      // a wave of the approach kernels = one pixel x 2^6 frames (VP_APPROACH_FRAMES_LOG2: 0 = 64 pixels of one frame)
@@ -140,6 +141,7 @@ struct State
     unsigned    h_bound_mask[8] = {};     // ... read back (ensure_bound_mask)
     // exit flights (render_k): per cell and class of directions, is every cell such a ray can meet empty?  Built with the volume
     bool        use_exit    = true;       // VP_NO_EXIT=1: every path walks to the box exit
+    bool        exit_local  = false;      // VP_EXIT_LOCAL=1: also for the local-majorant estimators (measured: nothing to gain there)
     unsigned    exit_k      = 8;          // null collisions in empty space before a lane asks for the test (VP_EXIT_K)
     unsigned char* d_exit   = nullptr;
     float       light_key[7] = {};
@@ -274,6 +276,7 @@ int ensure_device()
     if (knob("VP_LOOKAHEAD", 0, 4096, v)) G.la_max = (int)v;
     if (knob("VP_NO_LA_CANCEL", 0, 1, v)) G.la_cancel = v == 0;
     if (knob("VP_NO_EXIT", 0, 1, v)) G.use_exit = v == 0;
+    if (knob("VP_EXIT_LOCAL", 0, 1, v)) G.exit_local = v != 0;
     if (knob("VP_EXIT_K", 1, VP_EXIT_TRIP, v)) G.exit_k = (unsigned)v;
     G.dev_ready = true;
     return VP_OK;
@@ -697,7 +700,11 @@ int exit_flights(LaunchDev& L)
     if (!G.use_exit || !G.d_exit || !G.linear || G.trk || G.env_mis || G.est == VP_EST_BOUNDED) return VP_OK;
     if (G.est != VP_EST_GLOBAL)
     {
-        if (!G.quant) return VP_OK;
+        // Off by default: with local majorants the way out through empty bricks is a restart segment and ONE free flight per 0.05 of
+        // length, made by lanes that ride along with their wave's fetching lanes -- ending those paths early removes 11 % of the
+        // lane-steps of the decomposition workloads and not one wave-iteration (C3 +2 %, c3ref 0, c4s -0.5 %, sampler.h -1...-2 %:
+        // DESIGN.md section 5).  The global-majorant walk is 800 null collisions per unit length: there it is +27 %.
+        if (!G.exit_local || !G.quant) return VP_OK;
         int rc = ensure_bound_mask();
         if (rc) return rc;
         unsigned nb = 0, packed = 0;
@@ -874,6 +881,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         rc = ensure_light_const(p, &light_const);
         if (rc) return rc;
     }
+    G.last_light_const = light_const ? 1 : 0;
     if (G.est == VP_EST_GLOBAL && G.n_light && !light_const)
     {
         rc = ensure_thr_table(p, &L.thr_table);
@@ -1498,6 +1506,12 @@ int vp_set_rng(int mode, uint32_t k0, uint32_t k1)
     G.rng = mode; G.key0 = k0; G.key1 = k1;
     return VP_OK;
 }
+int vp_set_exit_flights(int mode)
+{
+    if (mode < 0 || mode > 2) return fail(VP_E_ARG, "exit flights: 0 off, 1 global-majorant estimator (default), 2 every estimator that has them");
+    G.use_exit = mode != 0; G.exit_local = mode == 2;
+    return VP_OK;
+}
 int vp_set_tracking(int mode)
 {
     if (mode != VP_TRACK_SPECTRAL && mode != VP_TRACK_SCALAR && mode != VP_TRACK_MULTI_CHANNEL)
@@ -1599,6 +1613,7 @@ int vp_render_time_ms(double* total_ms, int* launches, int reset)
     return VP_OK;
 }
 int vp_last_approach_mode(void) { return G.last_approach; }
+int vp_last_light_const(void) { return G.last_light_const; }
 int vp_render_class_time_ms(double ms[3], unsigned pixels[3], int reset)
 {
     int rc = ensure_device();

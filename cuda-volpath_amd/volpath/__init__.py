@@ -24,7 +24,7 @@ PART1_SYMBOLS = ["init_cuda", "set_texture_filter_mode", "free_cuda_buffers", "p
                  "render_kernel", "scale", "gamma_correct"]
 PART2_SYMBOLS = ["vp_last_error", "vp_version", "vp_device_count", "vp_set_device", "vp_set_stream", "vp_get_stream", "vp_synchronize",
                  "vp_set_estimator", "vp_set_rng", "vp_set_envmap_sampling", "vp_get_env_tables", "vp_set_lookahead", "vp_set_tracking", "vp_set_bound_brick", "vp_set_shard", "vp_render_frames",
-                 "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity", "vp_get_pixel_table", "vp_get_null_collision_table", "vp_get_sun_clip_table", "vp_get_exit_table", "vp_render_class_time_ms", "vp_last_approach_mode", "vp_prepare", "vp_get_pixel_lists",
+                 "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity", "vp_get_pixel_table", "vp_get_null_collision_table", "vp_get_sun_clip_table", "vp_get_exit_table", "vp_set_exit_flights", "vp_render_class_time_ms", "vp_last_approach_mode", "vp_prepare", "vp_get_pixel_lists",
                  "vp_julia_voxelize", "vp_cloud_voxelize", "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_test_hg", "vp_test_intersect_box",
                  "vp_test_eval_envmap", "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_current", "vp_ctx_get_current", "vp_ctx_device",
                  "vp_accumulate", "vp_tile_owner", "vp_malloc", "vp_free", "vp_memset",
@@ -325,6 +325,11 @@ def last_approach_mode():
     return int(lib().vp_last_approach_mode())
 
 
+def last_light_const():
+    """True if the last render call wrote its light pixel class as per-pixel constants (vp_last_light_const)"""
+    return bool(lib().vp_last_light_const())
+
+
 def prepare(P):
     """build the per-camera tables, pixel lists and sun table of the current state now (vp_prepare)"""
     _chk(lib().vp_prepare(C.byref(P)))
@@ -356,6 +361,11 @@ def sun_clip_table(shape):
     step = C.c_float()
     _chk(lib().vp_get_sun_clip_table(_p(out), out.size, C.byref(step)))
     return out, step.value
+
+
+def set_exit_flights(mode):
+    """0 off, 1 global-majorant estimator only (default), 2 also the decomposition estimator (include/volpath.h)"""
+    _chk(lib().vp_set_exit_flights(mode))
 
 
 def exit_table(shape):

@@ -129,7 +129,7 @@ def setup(workload, rng_mode=RNG_PHILOX, key=(0x9E3779B9, 0x85EBCA6B), rank=0, w
         mat(P, *PRESET1)
     if cfg["est"] == EST_DECOMP and opacity and last_frame > 10:
         precompute_opacity(sun_dir)  # host.cpp:336-343
-    info = dict(cfg, occupancy=float(grid.mean() / 255.0), sunsky=(env, sun_dir, sun_power), camera=cam)
+    info = dict(cfg, occupancy=float(grid.mean() / 255.0), sunsky=(env, sun_dir, sun_power), camera=cam, grid=grid)
     if cfg.get("volume", "julia") == "cloud":
         info["volume"] = f"{cfg['n']}^3 uchar, FLAGGED SYNTHETIC cloud (vp_cloud_voxelize seed {cfg['seed']}) through dump_dense_volume -> loadBinaryFile"
         info["note"] = "synthetic stand-in for the WDAS cloud (no data set, no OpenVDB in the image); frame-filling"

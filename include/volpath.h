@@ -202,6 +202,9 @@ int vp_render_class_time_ms(double ms[3], unsigned pixels[3], int reset);
  * certified-empty stretch ahead of it, 2 = as 1 with the walked throughput looked up by the number of steps (a global-majorant
  * medium whose null collision in empty space is not neutral).  Never changes a result. */
 int vp_last_approach_mode(void);
+/* 1 if the last render call of this context wrote its light class (pixels whose camera ray meets empty cells only) as per-pixel
+ * constants (miss_fill_k: a null collision in empty space leaves a throughput of 1 as it is in this medium), 0 if it integrated it. */
+int vp_last_light_const(void);
 /* Builds everything a render of this Param would build first -- the per-pixel tables of the current camera, the pixel lists
  * of the shard, the sun table -- and waits for it.  A host that moves the camera may call it to take that work out of its
  * first frame; bench.py times it (per_camera_setup_ms).  Not needed for correctness: render_kernel does the same on demand. */
@@ -231,6 +234,10 @@ int vp_get_sun_clip_table(unsigned short* dst, size_t count, float* step);
  * other two axes in increasing order: every cell a ray from anywhere in `cell` with a direction of that class can meet is empty and
  * has empty neighbours.  Test hook for the certificate; VP_NO_EXIT=1 switches the table off. */
 int vp_get_exit_table(unsigned char* dst, size_t count);
+/* 0: off (every path walks to the box exit); 1 (default): the global-majorant estimator, where that walk is 800 null collisions per
+ * unit length; 2: the decomposition estimator as well (uchar bound tables with at most four distinct maxima), where the walk is one
+ * free flight per restart segment and ending it early is not measurably faster.  Performance only: the same bits in every mode. */
+int vp_set_exit_flights(int mode);
 /* dst[n] = throughput of an unscattered path of the global-majorant estimator after n null collisions in empty space, n < count
  * (spectral tracking: the weight of such a collision is 1 only up to rounding; the light kernel looks the product up by n).
  * Test hook: the sequence is three float32 operations per step and can be restated anywhere. */

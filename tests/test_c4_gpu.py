@@ -607,7 +607,7 @@ def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
         dict(VP_NO_APPROACH="1"), dict(VP_NO_APPROACH_LOCAL="1"), dict(VP_APPROACH_STEPS="3"), dict(VP_APPROACH_STEPS="0"),
         dict(VP_APPROACH_STEPS="40", VP_NO_LDS_HELPER="1"), dict(VP_APPROACH_FRAMES_LOG2="0"), dict(VP_APPROACH_FRAMES_LOG2="1"),
         # exit flights (paths that can only leave the box are ended at once): off, tested at once, tested late
-        dict(VP_NO_EXIT="1"), dict(VP_EXIT_K="1"), dict(VP_EXIT_K="40"),
+        dict(VP_NO_EXIT="1"), dict(VP_EXIT_K="1"), dict(VP_EXIT_K="40"), dict(VP_EXIT_LOCAL="1"), dict(VP_EXIT_LOCAL="1", VP_EXIT_K="2"),
     ]
     for env_set in settings:
         saved = {k: os.environ.get(k) for k in env_set}

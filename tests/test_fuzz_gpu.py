@@ -140,6 +140,7 @@ def test_random_scene_bit_exact(vp, oracle, seed):
         vp.set_tracking(c["track"])
         vp.set_envmap_sampling(vp.ENV_MIS if c["env_mis"] else vp.ENV_PASSIVE)
         vp.set_shard(0, 1)
+        vp.set_exit_flights(seed % 3)             # exit flights: off / global-majorant estimator (default) / local majorants too
         if late:
             vp.precompute_opacity(sun_dir)
         counted = not c["track"]                  # the work counters are not built for the scalar tracking kernels
@@ -164,6 +165,7 @@ def test_random_scene_bit_exact(vp, oracle, seed):
     finally:
         vp.enable_counters(False)
         vp.set_shard(0, 1)
+        vp.set_exit_flights(1)
         vp.set_tracking(0)
         vp.set_envmap_sampling(0)
         vp.set_camera()
