@@ -32,7 +32,7 @@ if ks:
             r = max(sel, key=lambda r: float(r["TotalDurationNs"]))
             res[key] = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                         "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"])}
-for d in ("fetch", "write", "sq", "tcc"):
+for d in ("fetch", "write", "sq", "sq2", "tcc"):
     for f in glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(float); disp = collections.defaultdict(set)
         for r in csv.DictReader(open(f)):

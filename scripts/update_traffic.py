@@ -28,6 +28,16 @@ for wl in wls:
         raise SystemExit(f"{wl}: no kernel_stats.csv under {src}/kt matches the digest")
     shutil.copy(picked, os.path.join(ROOT, f"profiles/{tag}_{wl}_kernel_stats.csv"))
     sq, tcc, b = d["sq"]["per_launch"], d["tcc"]["per_launch"], d["bench_line_kt"]
+    sq2 = d.get("sq2", {}).get("per_launch", {})
+    # where the wave-cycles go (MI355X_MICROARCH.md, PMC section: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, disjoint) and
+    # what is issued besides vector arithmetic; all counters in units of four cycles, summed over the launch's kernels
+    stalls = {"wait_any_frac": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], "wait_inst_frac": sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]}
+    if sq2:
+        stalls.update({"active_inst_frac": sq2["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
+                       "salu_per_valu": sq2["SQ_INSTS_SALU"] / sq["SQ_INSTS_VALU"],
+                       "valu_per_vmem_read": sq["SQ_INSTS_VALU"] / max(sq2["SQ_INSTS_VMEM_RD"], 1.0),
+                       "branch_per_valu": sq2["SQ_INSTS_BRANCH"] / sq["SQ_INSTS_VALU"],
+                       "vmem_level_per_read": sq2["SQ_INST_LEVEL_VMEM"] / max(sq2["SQ_INSTS_VMEM_RD"], 1.0)})
     T[wl] = {
         "hbm_bytes_per_launch": d["hbm_bytes_per_launch"],
         "valu_insts_per_launch": sq["SQ_INSTS_VALU"],
@@ -41,6 +51,7 @@ for wl in wls:
                   "the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (HBM section), calibrated for this kernel's 8-byte gathers "
                   "(profiles/r01_fetch_calibration.txt); these counters sit on the L2's fabric side, so Infinity-Cache hits are INCLUDED: it is "
                   "an upper bound of the HBM bytes.  lane_util = SQ_THREAD_CYCLES_VALU / (64 * SQ_INSTS_VALU).",
+        "stalls": stalls,
         "source": dst, "commit": commit,
     }
 json.dump(T, open(tp, "w"), indent=1)
