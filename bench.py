@@ -130,9 +130,15 @@ def self_launch(args, argv):
     raise SystemExit(p.returncode)
 
 
-def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=True, rng=None, warmup_spp=None, count_frames=None):
+def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=True, rng=None, warmup_spp=None, count_frames=None,
+                 split="tiles"):
     """Time `steps` render jobs of one workload; returns the fields of the JSON line (rank 0) or None.
-    rng: the stream (default args.rng); warmup_spp: samples per pixel of a warm-up step (default: as a timed step)."""
+    rng: the stream (default args.rng); warmup_spp: samples per pixel of a warm-up step (default: as a timed step).
+    split: how N ranks share a step.  "tiles" (north_star): every rank renders ITS pixel tiles (vp_tile_owner) in all frames; the
+    accumulators are disjoint, so the reduce is exact and the image bit-identical to one rank's.  "frames" (SURVEY section 8e's
+    alternative): every rank renders ALL pixels in its contiguous share of the step's frames -- perfectly balanced whatever the
+    image -- and rank 0 adds the partial images IN RANK ORDER, ((p0 + p1) + p2) + ...: a defined result (tested against the same
+    sum made on one GPU), not the one-rank bits: binary32 addition does not associate."""
     import torch
     import torch.distributed as dist
     import volpath as vp
@@ -141,13 +147,16 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
     rng = rng or args.rng
     spp_step = spp_per_gpu * world if scaling == "weak" else spp_per_gpu
     warmup_spp = spp_step if warmup_spp is None else warmup_spp
+    by_frames = split == "frames" and world > 1
+    if by_frames and (spp_step % world or warmup_spp % world):
+        raise SystemExit(f"--split frames: {spp_step} samples per pixel do not divide over {world} ranks")
     rng_mode = {"philox": vp.RNG_PHILOX, "philox7": vp.RNG_PHILOX7, "samplerh": vp.RNG_SAMPLERH}[rng]
     cfg = vscene.WORKLOADS[workload]
     if count_frames is None:   # frames of the (untimed) work-counter pass
         count_frames = 4 if (cfg["est"] == vp.EST_GLOBAL or cfg["n"] > 256) else 8
     # the live kernel reads the optical-depth table from frame 11 on (quirk Q5): a job of hundreds of frames is counted there
     count_first = 16 if (cfg["est"] == vp.EST_DECOMP and spp_step * steps >= 64) else 0
-    P, info = vscene.setup(workload, rng_mode=rng_mode, rank=rank, world=world,
+    P, info = vscene.setup(workload, rng_mode=rng_mode, rank=0 if by_frames else rank, world=1 if by_frames else world,
                            last_frame=max(warmup_spp * warmup + spp_step * steps, count_first + count_frames), sunsky=ctx.setdefault("sunsky", None))
     ctx["sunsky"] = info["sunsky"]
     W, H = P.width, P.height
@@ -183,6 +192,19 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
 
         def step(first, spp):
             acc.zero_()
+            if by_frames:
+                # this rank's contiguous share of the step's frames, all pixels; partial images gathered and added in rank order
+                share = spp // world
+                vp.render_frames(acc.data_ptr(), first + rank * share, share, P)
+                part = acc.cpu() if rehearsal else acc
+                parts = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
+                dist.gather(part, parts, dst=0)
+                if rank == 0:
+                    total = parts[0].to(dev)
+                    for q in parts[1:]:
+                        total = total + q.to(dev)
+                    image.add_(total)
+                return
             vp.render_frames(acc.data_ptr(), first, spp, P)
             if world > 1 and rehearsal:
                 host = acc.cpu()
@@ -195,6 +217,9 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
 
         for i in range(warmup):
             step(i * warmup_spp, warmup_spp)
+        # buffers are sized before the clock starts, as the reference's host sizes its own at start-up: a short warm-up step must
+        # not leave a 15 GB hipMalloc to the first timed launch
+        vp.reserve_frames(P, (spp_step // world) if by_frames else spp_step)
         barrier()
         vp.render_time_ms(reset=True)
         vp.render_class_time_ms(reset=True)
@@ -221,7 +246,7 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
         return None
 
     samples_total = float(W) * H * spp_step * steps                 # all ranks together
-    frames_rank = spp_step * steps                                  # frames this rank rendered (of its own tiles)
+    frames_rank = (spp_step // world if by_frames else spp_step) * steps   # frames this rank rendered (of its own pixels)
     pixels_rank = sum(class_px.values())
     samples_rank = float(pixels_rank) * frames_rank
     value = samples_total / dt / 1e6
@@ -282,7 +307,8 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
                    "estimator": "global_majorant" if info["est"] == vp.EST_GLOBAL else "decomposition",
                    "bound_brick": info["brick"],
                    "rng": RNG_NAMES[rng],
-                   "parallelism": f"pixel-tiles x{world}" + (" + RCCL reduce" if world > 1 else ""),
+                   "parallelism": (f"frame-ranges x{world} + RCCL gather, partial images added in rank order" if by_frames else
+                                   f"pixel-tiles x{world}" + (" + RCCL reduce" if world > 1 else "")),
                    "sky": "Hosek sun/sky bake, setup_sunsky(0.5, 0.2), 1024x512"},
         # the class that does the physics: the pixels whose camera ray can meet the medium (the others are per-pixel constants in
         # this scene: quirk Q3, no pixel jitter) -- the number to track; `value` is BASELINE's metric, all pixels
@@ -372,6 +398,10 @@ def main():
                     help="weak: spp * N per step (per-GPU work fixed); strong: spp per step whatever N; both: the weak line with "
                          "the strong measurement inside it; auto (default): weak at N = 1, both at N > 1 (the fixed-job run costs "
                          "1/N of a weak step and shows the per-shard tail the weak line hides)")
+    ap.add_argument("--split", default="auto", choices=["auto", "tiles", "frames"],
+                    help="how the ranks share a FIXED job (--scaling strong / both): tiles = pixel tiles (north_star; the weak line always), "
+                         "frames = contiguous frame ranges of all pixels, partial images added in rank order; auto = measure both, report "
+                         "the better")
     ap.add_argument("--rng", default="philox7", choices=["philox", "philox7", "samplerh"],
                     help="philox7 = Philox2x32-7 (default: the fewest rounds Random123 documents as Crush-resistant; oracle parity "
                          "like the others), philox = Philox2x32-10 (the round-1 default, 4-6 %% slower), samplerh = the reference's "
@@ -416,10 +446,16 @@ def main():
     if args.scaling == "auto":
         args.scaling = "both" if world > 1 else "weak"
     first = "strong" if args.scaling == "strong" else "weak"
-    out = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, first)
-    strong = None
+    out = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, first,
+                       split="frames" if (first == "strong" and args.split == "frames") else "tiles")
+    strong, strong_alt = None, None
     if args.scaling == "both" and world > 1:
-        strong = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, "strong", full=False)
+        # the fixed job (spp whatever N) both ways where the frames divide: by pixel tiles (every shard pays the tail of its own
+        # deepest paths and a few per cent of imbalance) and by frame ranges (balanced by construction, every rank pays the fixed
+        # cost of a launch); the better one is reported, the other kept beside it
+        strong = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, "strong", full=False, split="tiles")
+        if args.split in ("auto", "frames") and args.spp % world == 0:
+            strong_alt = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, "strong", full=False, split="frames")
     secondary = {}
     if world == 1 and args.workload == "c2" and not args.no_secondary:
         # The workloads that do physics in every pixel, or on the reference's own streams, under the same clock as the headline
@@ -450,10 +486,18 @@ def main():
         image = out.pop("_image")
         grid = out.pop("_grid")
         if strong:
-            strong.pop("_image")
-            strong.pop("_grid")
-            out["strong"] = {k: strong[k] for k in ("value", "unit", "ms_per_step", "scaling", "per_class", "ranks") if k in strong}
-            out["strong"]["spp_per_step"] = strong["config"]["spp_per_step"]
+            both = {"tiles": strong}
+            if strong_alt:
+                both["frames"] = strong_alt
+            for q in both.values():
+                q.pop("_image")
+                q.pop("_grid")
+            best = max(both, key=lambda k: both[k]["value"]) if args.split == "auto" else ("frames" if (args.split == "frames" and strong_alt) else "tiles")
+            out["strong"] = {k: both[best][k] for k in ("value", "unit", "ms_per_step", "scaling", "per_class", "ranks") if k in both[best]}
+            out["strong"]["spp_per_step"] = both[best]["config"]["spp_per_step"]
+            out["strong"]["split"] = best
+            out["strong"]["by_split"] = {k: {"value": v["value"], "ms_per_step": v["ms_per_step"], "parallelism": v["config"]["parallelism"],
+                                             "balance_max_over_mean": v.get("ranks", {}).get("balance_max_over_mean")} for k, v in both.items()}
         if secondary:
             out["secondary"] = secondary
         if args.dump_image:

@@ -62,6 +62,8 @@ struct State
         std::vector<unsigned char> key;
     } la[2];
     hipStream_t ctrl_stream = nullptr; // la_quiesce: tells batches in flight to stop handing out samples
+    unsigned*   d_cancel    = nullptr; // [3] per render target: the newest batch number of the slot that is cancelled (LaunchDev::cancel)
+    unsigned    batch_seq[3] = {0, 0, 0};   // number of the last batch queued on each target
     bool        la_cancel   = true;    // VP_NO_LA_CANCEL=1: batches in flight always run to their end
     int         la_prev_n   = 0;      // batch size of the last miss
     int         la_last     = -2;     // frame index of the last render_kernel call
@@ -228,6 +230,8 @@ int ensure_device()
     HIPCHK(hipMalloc((void**)&G.d_queue, 6 * kQueueWords * sizeof(unsigned)));  // (caller's stream + two look-ahead slots) x two tile classes
     HIPCHK(hipMalloc((void**)&G.d_counters, kCounterWords * sizeof(unsigned long long)));
     HIPCHK(hipMemset(G.d_counters, 0, kCounterWords * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void**)&G.d_cancel, 3 * sizeof(unsigned)));
+    HIPCHK(hipMemset(G.d_cancel, 0, 3 * sizeof(unsigned)));
     G.S.sun_cos = 94.0f / sqrtf(94.0f * 94.0f + 0.45f * 0.45f);                    // kernel.cu:1263
     G.S.cam_z   = (float)(-1.0f / tan((double)54.43f * 0.00872664626));             // kernel.cu:1981-1985
     // tuning knobs (performance only; results never depend on them).  Out-of-range or malformed values are ignored:
@@ -511,6 +515,7 @@ struct ClassTimer
         ok = a && b && hipEventRecord(a, st) == hipSuccess;
         if (!ok) (void)hipGetLastError();
     }
+    ~ClassTimer() { put_event(a); put_event(b); }   // a timer that was never stopped (an early return) hands its events back
     void stop()
     {
         if (ok && hipEventRecord(b, st) == hipSuccess) { G.class_events.push_back({cls, a, b}); a = b = nullptr; }
@@ -875,6 +880,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     L.count_clips = getenv("VP_DEBUG_COUNT_CLIPS") ? 1u : 0u;
     rc = exit_flights(L);
     if (rc) return rc;
+    // look-ahead batches carry their slot's cancel word and their number (la_render_slot, la_quiesce); the caller's own launches cannot be cancelled
+    L.cancel = tgt ? G.d_cancel + T.index : nullptr; L.batch_id = G.batch_seq[T.index];
     bool light_const = false;
     if (G.n_light)
     {
@@ -914,6 +921,22 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     size_t max_f = (nframes > 1 || stage_only) ? stage_frames_cap(per_frame, *T.stage_bytes) : 1;
     SceneDev S = G.S;
     S.linear   = G.linear ? 1 : 0;
+    // sampler.h's state is two words and the staging slot of the decomposition estimator's hand-over holds the segment origin and one:
+    // the other goes beside it.  Sized ONCE, before the launch loop (no synchronisation, no early return between a launch's events).
+    const bool appr_aux_needed = approach && G.est == VP_EST_DECOMP && G.rng == VP_RNG_SAMPLERH && (nframes > 1 || stage_only);
+    if (appr_aux_needed)
+    {
+        const int    ti    = T.index;
+        const size_t need4 = per_frame * std::min<size_t>((size_t)nframes, max_f) * sizeof(unsigned);
+        if (need4 > G.appr_aux_bytes[ti])
+        {
+            HIPCHK(hipStreamSynchronize(T.stream));
+            if (G.d_appr_aux[ti]) HIPCHK(hipFree(G.d_appr_aux[ti]));
+            G.d_appr_aux[ti] = nullptr; G.appr_aux_bytes[ti] = 0;
+            if (hipMalloc((void**)&G.d_appr_aux[ti], need4) != hipSuccess) { (void)hipGetLastError(); G.d_appr_aux[ti] = nullptr; }   // no walk ahead then
+            else G.appr_aux_bytes[ti] = need4;
+        }
+    }
     for (int done = 0; done < nframes;)
     {
         int f = (int)std::min<size_t>((size_t)(nframes - done), max_f);
@@ -1046,22 +1069,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                 ClassTimer ct(0, T.stream);
                 L.approach = 0;
                 G.last_approach = 0;
-                bool aux_ok = true;
-                if (approach && L.stage && G.est == VP_EST_DECOMP && G.rng == VP_RNG_SAMPLERH)
-                {
-                    // sampler.h's state is two words and the staging slot holds the segment origin and one: the other goes beside it
-                    const int    ti    = T.index;
-                    const size_t need4 = per_frame * (size_t)f * sizeof(unsigned);
-                    if (need4 > G.appr_aux_bytes[ti])
-                    {
-                        HIPCHK(hipStreamSynchronize(T.stream));
-                        if (G.d_appr_aux[ti]) HIPCHK(hipFree(G.d_appr_aux[ti]));
-                        G.d_appr_aux[ti] = nullptr; G.appr_aux_bytes[ti] = 0;
-                        if (hipMalloc((void**)&G.d_appr_aux[ti], need4) != hipSuccess) { (void)hipGetLastError(); G.d_appr_aux[ti] = nullptr; aux_ok = false; }
-                        else G.appr_aux_bytes[ti] = need4;
-                    }
-                    L.approach_aux = G.d_appr_aux[ti];
-                }
+                const bool aux_ok = !appr_aux_needed || G.d_appr_aux[T.index] != nullptr;
+                if (appr_aux_needed) L.approach_aux = G.d_appr_aux[T.index];
                 if (approach && aux_ok && L.stage && f <= 65535)
                 {
                     L.approach       = approach_thr ? 2u : 1u;
@@ -1158,10 +1167,12 @@ int la_quiesce()
 {
     // Every caller is about to drop the staged frames (a setter, a camera move, new device contents): what a batch still in
     // flight would render is of no use -- unless a frame of it has already been handed out (its add-kernel sits on the caller's
-    // stream behind the batch's completion event and needs that frame whole: such a batch runs to its end).  Their sample queues are told that everything is handed out -- the queue heads jump past
-    // any chunk count (0x80000000; a wave that asks gets "band exhausted") -- so the kernels drain the paths already running
-    // and end: a camera move waits a millisecond or two instead of the rest of a 64-frame batch.  Written from a stream of its
-    // own (the batch's stream is busy with the batch); results are discarded, so nothing depends on where the cut falls.
+    // stream behind the batch's completion event and needs that frame whole: such a batch runs to its end).  The slot's cancel
+    // word gets the batch's number: its render_k takes no further chunk (it asks at every chunk, in every launch of a multi-launch
+    // batch), approach kernels that have not started yet return at once, and the kernels drain the paths already running: a
+    // camera move waits a millisecond or two instead of the rest of a 64-frame batch.  Numbers only grow, so nothing has to be
+    // re-armed and a cancel can neither be lost to a memset queued behind it nor reach a later batch.  Written from a
+    // stream of its own (the batch's stream is busy with the batch); results are discarded, so nothing depends on where the cut falls.
     bool any = false;
     bool cancel[2] = {false, false};
     for (int si = 0; si < 2 && G.la_cancel; si++)
@@ -1174,7 +1185,7 @@ int la_quiesce()
         {
             for (int si = 0; si < 2; si++)
                 if (cancel[si])
-                    (void)hipMemsetD32Async((hipDeviceptr_t)(G.d_queue + 2 * kQueueWords * (si + 1)), (int)0x80000000u, 2 * kQueueWords, G.ctrl_stream);
+                    (void)hipMemsetD32Async((hipDeviceptr_t)(G.d_cancel + (si + 1)), (int)G.batch_seq[si + 1], 1, G.ctrl_stream);
             (void)hipGetLastError();
         }
     }
@@ -1205,6 +1216,7 @@ int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, c
     HIPCHK(hipStreamWaitEvent(s.stream, ev, 0));
     put_event(ev);
     const Target t = {s.stream, &s.buf, &s.bytes, G.d_queue + 2 * kQueueWords * (si + 1), si + 1};
+    G.batch_seq[si + 1]++;   // (numbers only grow: a cancel of an earlier batch of this slot can never reach this one)
     int rc = do_render(d_out, first, n, p, true, &t);
     if (rc) return rc;
     HIPCHK(hipEventRecord(s.done, s.stream));
@@ -1452,6 +1464,7 @@ int vp_ctx_destroy(vp_ctx* ctx)
         if (D.ctrl_stream) (void)hipStreamDestroy(D.ctrl_stream);
         if (D.d_queue) (void)hipFree(D.d_queue);
         if (D.d_counters) (void)hipFree(D.d_counters);
+        if (D.d_cancel) (void)hipFree(D.d_cancel);
         if (D.own_stream) (void)hipStreamDestroy(D.own_stream);
     }
     t_current = (prev == &ctx->st) ? nullptr : prev;
@@ -1685,6 +1698,41 @@ int vp_prepare(const Param* p)
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(G.stream));
+    return VP_OK;
+}
+int vp_reserve_frames(const Param* p, int nframes)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || nframes <= 0) return fail(VP_E_ARG, "vp_reserve_frames: bad arguments");
+    if (p->width == 0 || p->height == 0 || p->width > 65535 || p->height > 65535) return fail(VP_E_ARG, "image %ux%u out of range", p->width, p->height);
+    const Shard sh = shard_of(p);
+    if (sh.per_frame == 0 || nframes == 1) return VP_OK;
+    // what do_render would allocate for the first launch of such a job (a one-frame call accumulates directly and stages nothing)
+    const size_t f    = std::min<size_t>((size_t)nframes, stage_frames_cap(sh.per_frame, G.stage_bytes));
+    const size_t need = sh.per_frame * f * sizeof(float4);
+    // (sampler.h + decomposition estimator: the second word of the stream's state beside each staging slot, do_render)
+    const size_t need4 = (G.est == VP_EST_DECOMP && G.rng == VP_RNG_SAMPLERH && G.use_approach && G.use_approach_local) ? sh.per_frame * f * sizeof(unsigned) : 0;
+    if (need4 > G.appr_aux_bytes[0])
+    {
+        HIPCHK(hipStreamSynchronize(G.stream));
+        if (G.d_appr_aux[0]) HIPCHK(hipFree(G.d_appr_aux[0]));
+        G.d_appr_aux[0] = nullptr; G.appr_aux_bytes[0] = 0;
+        if (hipMalloc((void**)&G.d_appr_aux[0], need4) != hipSuccess) { (void)hipGetLastError(); G.d_appr_aux[0] = nullptr; }
+        else G.appr_aux_bytes[0] = need4;
+    }
+    if (need <= G.stage_bytes) return VP_OK;
+    if (la_quiesce()) return VP_E_NODEVICE;
+    HIPCHK(hipStreamSynchronize(G.stream));
+    if (G.d_stage) HIPCHK(hipFree(G.d_stage));
+    G.d_stage = nullptr; G.stage_bytes = 0;
+    if (hipMalloc((void**)&G.d_stage, need) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        G.d_stage = nullptr;
+        return VP_OK;   // the render call will stage smaller batches: same bits
+    }
+    G.stage_bytes = need;
     return VP_OK;
 }
 int vp_get_bound_table(void* dst, size_t bytes, int* bnx, int* bny, int* bnz, int* brick, int* radius)

@@ -117,6 +117,11 @@ struct LaunchDev
                               // VP_EXIT_TRIP - K (VP_EXIT_K); far below zero when the test is off
     unsigned exit_nbytes;     // local-majorant estimators: how many distinct bytes occur as maxima in the bound table (1..4, else off) ...
     unsigned exit_bytes;      // ... and the bytes, packed: every majorant a segment in empty cells can have
+    // Look-ahead batches (render_kernel's staged frames) can be told to stop: the host writes the number of the newest batch of this
+    // slot that is no longer wanted into *cancel (numbers only grow: nothing is ever re-armed); a batch whose number is not above it
+    // hands out no more samples -- render_k asks at every chunk it takes, the approach kernels when they start.  Null = never cancelled.
+    unsigned* cancel;
+    unsigned  batch_id;
 };
 
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,

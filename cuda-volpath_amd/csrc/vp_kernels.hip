@@ -649,7 +649,9 @@ void render_k(SceneDev S, LaunchDev L)
                         unsigned c = 0xffffffffu;
                         if (len)
                         {
-                            if (lane == 0) c = atomicAdd(L.queue + q_cur * VP_QUEUE_STRIDE, 1u);
+                            // (a cancelled look-ahead batch hands out nothing more: an atomic read, so that the host's write from another
+                            // stream is seen whichever XCD this wave runs on)
+                            if (lane == 0 && !(L.cancel && atomicOr(L.cancel, 0u) >= L.batch_id)) c = atomicAdd(L.queue + q_cur * VP_QUEUE_STRIDE, 1u);
                             c = __builtin_amdgcn_readfirstlane(c);
                         }
                         if (c < cpf * fblocks)
@@ -1589,9 +1591,19 @@ __global__ __launch_bounds__(256) void miss_fill_k(SceneDev S, LaunchDev L, int 
 // stops BEFORE the first flight that would pass t_empty or leave the box and leaves (distance reached, pairs used) in the sample's
 // staging slot; render_k takes the sample up from there and makes that flight itself (its own test `dist < t_empty` is still in
 // place: any prefix of the walk is a valid hand-over, so the step cap below costs nothing but the steps left over).
+// a look-ahead batch that was cancelled before its walk began (LaunchDev::cancel): one atomic read per wave; render_k, which then
+// hands out no sample, never reads the slots this walk would have written
+__device__ __forceinline__ bool approach_cancelled(const LaunchDev& L)
+{
+    if (!L.cancel) return false;
+    unsigned w = 0;
+    if ((threadIdx.x & 63u) == 0u) w = atomicOr(L.cancel, 0u);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)w) >= L.batch_id;
+}
 template <class RNG>
 __global__ __launch_bounds__(256) void approach_k(SceneDev S, LaunchDev L)
 {
+    if (approach_cancelled(L)) return;
     // a wave = ONE pixel in 64 consecutive frames where the launch has that many (fewer frames: 2^k frames x 64 / 2^k pixels): the
     // lanes share the ray, its certificate and the bricks it crosses, and differ only in what they draw -- their walks have
     // the same length up to the noise of a sum of exponentials
@@ -1641,6 +1653,7 @@ __global__ __launch_bounds__(256) void approach_k(SceneDev S, LaunchDev L)
 template <class RNG, bool QUANT>
 __global__ __launch_bounds__(256) void approach_local_k(SceneDev S, LaunchDev L)
 {
+    if (approach_cancelled(L)) return;
     const unsigned sh   = L.approach_fshift;   // (a wave = one pixel in 2^sh frames, as in approach_k)
     const unsigned slot = blockIdx.x * (256u >> sh) + (threadIdx.x >> sh), fl = (blockIdx.y << sh) + (threadIdx.x & ((1u << sh) - 1u));
     if (slot >= L.nslots || fl >= (unsigned)L.nframes) return;

@@ -106,10 +106,17 @@ enum { VP_EST_GLOBAL = 0, /* __d_render, kernel.cu:1285-1591: global majorant (B
        VP_EST_DECOMP = 1, /* __d_render_bounded_decomp, kernel.cu:1958-2318: the reference's live kernel */
        VP_EST_BOUNDED = 2 /* __d_render_bounded, kernel.cu:1667-1952: local majorant, no control component,
                              800 tracked segments at most, heat = segments * 0.001, never reads the opacity volume */ };
-enum { VP_RNG_SAMPLERH = 0, /* src/sampler.h bit-compatible streams (parity mode) */
-       VP_RNG_PHILOX   = 1, /* Philox2x32-10, counter = (draw/2, x<<16|y), key = (frame ^ key0) + key1; shadow rays draw from
-                               sub-streams: counter word 0 = 0x80000000 + ((2 * depth + ray) << 20) + step */
-       VP_RNG_PHILOX7  = 2  /* Philox2x32-7 (the fewest rounds Random123 documents as Crush-resistant), same counter / key;
+enum { VP_RNG_SAMPLERH = 0, /* src/sampler.h bit-compatible streams: THE PARITY MODE -- the reference's generator, seeding and order of
+                               draws (sampler.h:3-46; Tr_spectral draws from the path's own sequential stream), i.e. what a run of the
+                               reference computes sample for sample up to the arithmetic contract of DESIGN.md section 2 */
+       VP_RNG_PHILOX   = 1, /* Philox2x32-10, counter = (draw/2, x<<16|y), key = (frame ^ key0) + key1.  SAME ESTIMATOR, BUILD-DEFINED
+                               STREAM (north_star: a counter-based generator replaces sampler.h): same free flights, collision tests and
+                               transmittance flags, but shadow rays draw from sub-streams -- counter word 0 = 0x80000000 +
+                               ((2 * depth + ray) << 20) + step, 2^20 pairs each: a shadow ray of more steps (a majorant above 3e5 per
+                               unit length; the default medium has 800) would run into the next sub-stream -- and the phase function is
+                               sampled before the shadow ray.  Defined by oracle/vp_oracle.c; tied to the sampler.h images statistically
+                               (tests/test_parity_gpu.py::test_full_size_estimators_and_builds_converge_to_one_image) */
+       VP_RNG_PHILOX7  = 2  /* Philox2x32-7 (the fewest rounds Random123 documents as Crush-resistant), same counter / key / sub-streams;
                                built for the shipped configuration (spectral tracking, passive environment) */ };
 
 const char* vp_last_error(void);
@@ -209,6 +216,10 @@ int vp_last_light_const(void);
  * of the shard, the sun table -- and waits for it.  A host that moves the camera may call it to take that work out of its
  * first frame; bench.py times it (per_camera_setup_ms).  Not needed for correctness: render_kernel does the same on demand. */
 int vp_prepare(const Param* p);
+/* Sizes the per-launch sample staging for a coming vp_render_frames(…, n_frames, p) job of this context now (the reference's host
+ * allocates its buffers at start-up too): the first launch of the job then finds its buffer instead of allocating up to 16 GiB
+ * inside the caller's timed region.  Optional; never changes a result; does nothing for one-frame calls. */
+int vp_reserve_frames(const Param* p, int n_frames);
 /* test hook: the pixel lists of this context for p (after vp_prepare): dst[0 .. counts[0]) the general pixels, then counts[1]
  * light ones, then counts[2] whose camera ray misses the box, each y << 16 | x in tile order; dst may be NULL to ask for the counts */
 int vp_get_pixel_lists(const Param* p, uint32_t* dst, size_t count, unsigned counts[3]);

@@ -91,6 +91,7 @@ typedef struct
     uint32_t buf[2];
     uint32_t n; /* philox: pairs so far */
     uint32_t n_saved; /* philox: position of the path's own stream while a shadow ray draws from its sub-stream */
+    uint32_t n_base;  /* ... and where that sub-stream began */
     uint64_t* draws;
 } rng_t;
 
@@ -164,10 +165,17 @@ static inline void rng_enter_shadow(rng_t* r, uint32_t id)
     if (r->mode == VPO_RNG_SAMPLERH) return;
     r->n_saved = r->n;
     r->n       = 0x80000000u + (id << 20);
+    r->n_base  = r->n;
 }
+/* A sub-stream holds 2^20 pairs: a shadow ray that draws more would run into the sub-stream of the next scatter depth.  It would
+ * take a majorant above 3e5 per unit length (the default medium: 800) -- counted here, where every shadow ray is walked to its end,
+ * so that the tests can say it never happened (vpo_debug_shadow_overflow). */
+static uint64_t g_shadow_overflow = 0;
+uint64_t vpo_debug_shadow_overflow(void) { return __atomic_load_n(&g_shadow_overflow, __ATOMIC_RELAXED); }
 static inline void rng_leave_shadow(rng_t* r)
 {
     if (r->mode == VPO_RNG_SAMPLERH) return;
+    if (r->n - r->n_base > (1u << 20)) __atomic_fetch_add(&g_shadow_overflow, 1, __ATOMIC_RELAXED);
     r->n = r->n_saved;
 }
 

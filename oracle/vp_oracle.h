@@ -113,6 +113,7 @@ float    vpo_sample_density(const vpo_scene* S, const float pos[3]);
 void     vpo_sample_bound(const vpo_scene* S, const float pos[3], float out_max_min[2]);
 float    vpo_sample_opacity(const vpo_scene* S, const float pos[3]);
 void     vpo_build_env_tables(const float* env, int width, int height, float* cdf_y, float* cdf_x, float* pdfnorm_alt);
+uint64_t vpo_debug_shadow_overflow(void); /* test hook: shadow rays that drew more than the 2^20 pairs of their sub-stream (must stay 0) */
 uint64_t vpo_debug_mis_zero_pdf(void); /* test hook: zero-pdf `continue`s taken so far (kernel.cu:2266) */
 void     vpo_eval_envmap(const vpo_scene* S, const float dir[3], float rgb[3]);
 void     vpo_hg_sample(float g, const float n[3], float u0, float u1, float out[3]);

@@ -151,6 +151,8 @@ def test_random_scene_bit_exact(vp, oracle, seed):
         k = vp.read_counters()
         vp.enable_counters(False)
         assert np.array_equal(got, ref, equal_nan=True), (what, float(np.nanmax(np.abs(got - ref))))
+        # no shadow ray of the oracle's render outran the 2^20 pairs of its sub-stream (include/volpath.h, VP_RNG_PHILOX)
+        assert oracle.lib().vpo_debug_shadow_overflow() == 0, what
         if counted:
             for q in ("samples", "density_lookups", "bound_lookups", "opacity_lookups", "env_lookups", "scatters"):
                 assert k[q] == cnt[q], (what, q, k[q], cnt[q])

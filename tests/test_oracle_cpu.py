@@ -345,3 +345,56 @@ def test_julia_silhouette_matches_the_references_own_screenshot(oracle):
     far = np.array(cam, np.float32).reshape(3, 4).copy()
     far[:, 3] += 0.2 * far[:, 2]
     assert _iou(m2, silhouette(far.ravel())) < good - 0.07
+
+
+def _interior_stats(img, mask, ref_lum, ref_cnt, B):
+    """block-mean luminance of `img` (linear, per sample) inside `mask`, clamped at 1 like the display, against the screenshot's:
+    Pearson correlation at the exposure scale that minimises the residual, that scale, the rms residual"""
+    H, W = mask.shape
+    by, bx = H // B, W // B
+    cnt = mask.reshape(by, B, bx, B).sum((1, 3))
+    use = (ref_cnt >= ref_cnt.max() // 2) & (cnt > 0)
+    w = np.array([0.2126, 0.7152, 0.0722])
+
+    def block_lum(scale):
+        lum = np.minimum(img * scale, 1.0) @ w
+        return ((lum * mask).reshape(by, B, bx, B).sum((1, 3)) / np.maximum(cnt, 1))[use]
+    r = ref_lum[use].astype(np.float64)
+    scales = np.geomspace(0.25, 4.0, 241)
+    err = [float(((block_lum(sc) - r) ** 2).mean()) for sc in scales]
+    k = int(np.argmin(err))
+    return float(np.corrcoef(block_lum(scales[k]), r)[0, 1]), float(scales[k]), float(np.sqrt(err[k])), int(use.sum())
+
+
+def test_julia_interior_matches_the_references_own_screenshot(oracle):
+    """The first RADIOMETRIC pin the reference holds: what its Julia screenshot 2.jpg shows INSIDE the silhouette.
+    tests/golden/ref_julia_interior.npz = per 16x16 block the mean of the screenshot's pixels, linearised through the display's
+    gamma 2.2 (made by tests/golden/make_julia_interior.py), and the sun position fitted to them (tests/golden/fit_julia_sun.py: the
+    viewer's sun, like its camera, is moved with the mouse and not recorded -- TWO parameters against 345 blocks; the environment is
+    the uniform 0.03 grey of the screenshot's background, host.cpp:1374-1385; the exposure is NOT fitted).  With the reference's default
+    medium (density 800, g 0.877, albedo 1: host.cpp:1286-1292) the oracle's render of that scene reproduces the screenshot's shading:
+    Pearson correlation of the block luminances >= 0.98 (0.996 on the GPU at full resolution and 128 spp) at an exposure scale of
+    0.87 -- the absolute radiance, with the reference's own solar radiance and no free scale, is 13 % above the screenshot's.  That
+    is sun power x phase function x albedo x transmittance x multiple scattering x display transform against a reference OUTPUT; the
+    GPU test of the same name shows what it excludes (g = 0: rms residual 4.5x; density 80: 8x; albedo 0.8: 8x).
+    Half resolution, frames 0-9 (the live kernel before its switch to the optical-depth table): a few seconds."""
+    import os
+    O = oracle
+    mask, cam, pose, centre = _ref_silhouette()
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_julia_interior.npz"))
+    B = int(z["block"])
+    grid = O.julia(256)
+    env = np.full((8, 16, 4), 0.03, np.float32)
+    env[..., 3] = 1.0
+    osc = O.OracleScene(grid, env, tuple(float(v) for v in z["sun_dir"]), tuple(float(v) for v in z["sun_power"]), estimator=O.EST_DECOMP,
+                        rng_mode=O.RNG_PHILOX7, seed=(1, 2), inv_view=cam)
+    P = O.default_param(480, 256)
+    acc, frames = None, 10
+    for f in range(frames):
+        acc, _ = osc.render_frame(P, f, acc)
+    m2 = mask.reshape(256, 2, 480, 2).mean(axis=(1, 3)) >= 0.5
+    pear, scale, rms, nb = _interior_stats(acc[..., :3].astype(np.float64) / frames, m2, z["luminance"], z["count"], B // 2)
+    assert nb > 300
+    assert pear >= 0.98, (pear, scale, rms)
+    assert 0.78 <= scale <= 0.97, scale
+    assert rms <= 0.035, rms

@@ -299,16 +299,23 @@ def test_full_size_estimators_and_builds_converge_to_one_image(vp):
     one, are estimators of the SAME image.  192 spp each on Julia 256^3 at 800x600; compared on 40x40-pixel block means
     (1 % of the image mean + 4 standard errors of the pair) and on the whole-image mean.  The live kernel and its builds
     agree to 0.2 %; so do the two kernels without the optical-depth table; between the groups stands the bias of that
-    table (quirk Q5: deep scatters after frame 10 use a dt = 0.001 march instead of a tracked shadow ray), 0.3-0.7 %."""
+    table (quirk Q5: deep scatters after frame 10 use a dt = 0.001 march instead of a tracked shadow ray), 0.3-0.7 %.
+    The STREAMS as well: the counter-based streams changed the random process in oracle and kernel together (shadow rays
+    on sub-streams, the phase function sampled before the shadow ray, sun rays ended where only empty cells are left), so bit-equality
+    with the oracle no longer ties them to the reference's order of draws -- sampler.h mode does.  The Philox2x32-10 and -7 images of
+    the global-majorant and the live kernel must be the sampler.h images within the same Monte-Carlo bounds."""
     from volpath import scene as vscene
     frames = 192
     images = {}
     try:
-        for name, est, track, envm in (("decomp", 1, 0, 0), ("global", 0, 0, 0), ("bounded", 2, 0, 0), ("decomp_mis", 1, 0, 1),
-                                       ("decomp_scalar", 1, 1, 0), ("decomp_multichannel", 1, 2, 0)):
+        for name, est, track, envm, rng in (("decomp", 1, 0, 0, vp.RNG_PHILOX), ("global", 0, 0, 0, vp.RNG_PHILOX), ("bounded", 2, 0, 0, vp.RNG_PHILOX),
+                                            ("decomp_mis", 1, 0, 1, vp.RNG_PHILOX), ("decomp_scalar", 1, 1, 0, vp.RNG_PHILOX),
+                                            ("decomp_multichannel", 1, 2, 0, vp.RNG_PHILOX),
+                                            ("decomp_samplerh", 1, 0, 0, vp.RNG_SAMPLERH), ("global_samplerh", 0, 0, 0, vp.RNG_SAMPLERH),
+                                            ("decomp_philox7", 1, 0, 0, vp.RNG_PHILOX7), ("global_philox7", 0, 0, 0, vp.RNG_PHILOX7)):
             vp.set_tracking(track)
             vp.set_envmap_sampling(envm)
-            P, info = vscene.setup("c3ref", rng_mode=vp.RNG_PHILOX, key=(11, est * 7 + track * 3 + envm), last_frame=frames)
+            P, info = vscene.setup("c3ref", rng_mode=rng, key=(11, est * 7 + track * 3 + envm), last_frame=frames)
             vp.set_estimator(est)
             buf = vp.DeviceBuffer(800, 600)
             vp.render_frames(buf.ptr, 0, frames, P)
@@ -332,6 +339,10 @@ def test_full_size_estimators_and_builds_converge_to_one_image(vp):
         same_image(name, "decomp", 2e-3, 0.01)
     same_image("bounded", "global", 2e-3, 0.01)
     same_image("global", "decomp", 1.2e-2, 0.03)   # across the Q5 approximation
+    # the reference's own streams against the counter-based ones, estimator by estimator
+    for est in ("decomp", "global"):
+        same_image(est, est + "_samplerh", 2e-3, 0.01)
+        same_image(est + "_philox7", est + "_samplerh", 2e-3, 0.01)
 
 
 def test_cli_render_matches_oracle_ppm(vp, oracle, tmp_path):
@@ -709,6 +720,49 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path):
     assert line2["strong"]["scaling"] == "strong" and line2["strong"]["spp_per_step"] == 4 and line2["strong"]["value"] > 0
     assert len(line2["ranks"]["kernel_ms"]) == 2
     assert np.array_equal(np.load(one), np.load(two))
+
+
+def test_bench_frame_split_adds_partial_images_in_rank_order(vp, tmp_path):
+    """bench.py --scaling strong --split frames (SURVEY section 8e's sample split: every rank renders ALL pixels in its contiguous
+    share of the frames; the partial images are gathered and added in rank order on rank 0).  binary32 addition does not associate,
+    so the result is DEFINED as ((p0 + p1) + ...): two ranks on this one GPU (rehearsal) must produce exactly the sum of the two
+    partial images rendered here in one process -- and --split auto must report both ways of sharing the fixed job."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from volpath import scene as vscene
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    two = str(tmp_path / "two.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["VP_BENCH_REHEARSAL"] = "1"
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--workload", "c1", "--gpus", "2", "--spp", "8"]
+    r = subprocess.run([sys.executable, bench, "--scaling", "strong", "--split", "frames", "--dump-image", two] + common,
+                       capture_output=True, text=True, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and "frame-ranges x2" in line["config"]["parallelism"] and line["config"]["spp_per_step"] == 8
+    P, info = vscene.setup("c1", rng_mode=vp.RNG_PHILOX7, last_frame=8)
+    parts = []
+    for first in (0, 4):
+        buf = vp.DeviceBuffer(P.width, P.height)
+        vp.render_frames(buf.ptr, first, 4, P)
+        parts.append(buf.download())
+        buf.free()
+    got = np.load(two)
+    assert np.array_equal(got, parts[0] + parts[1])
+    buf = vp.DeviceBuffer(P.width, P.height)
+    vp.render_frames(buf.ptr, 0, 8, P)
+    one = buf.download()
+    buf.free()
+    assert np.allclose(got, one, rtol=1e-5, atol=1e-6) and not np.array_equal(got, one)    # same estimate, not the one-rank bits
+    r = subprocess.run([sys.executable, bench, "--scaling", "both", "--split", "auto"] + common, capture_output=True, text=True, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert set(line["strong"]["by_split"]) == {"tiles", "frames"} and line["strong"]["split"] in ("tiles", "frames")
+    assert line["scaling"] == "weak" and len(line["ranks"]["kernel_ms"]) == 2
+    vp.set_camera()
 
 
 @pytest.mark.parametrize("quantized", [True, False])
