@@ -980,6 +980,9 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         // (not for look-ahead batches: two of them overlap -- the next one's approach walk and first workgroups run beside the current
         // one's body and tail -- only if the current one leaves registers free: four LDS-table waves per SIMD do, the helper's fifth does
         // not.  C3 host loop 1301 -> 1510 Msamples/s without it, profiles/r03_render_kernel_lookahead.txt)
+        // COUPLING (two tuning decisions that depend on each other): approach_local_k needs 45 vector registers (kernel_resources.py);
+        // beside four 97-102-register LDS-table waves AND the helper's fifth 96-register wave a SIMD has 27 left, beside the four
+        // alone 124.  If approach_local_k's register count or the helper's occupancy changes, re-measure the `!tgt` below.
         const bool lds_helper = lds_bounds && G.lds_helper && G.n_general && !(G.n_light && !light_const) && !tgt;
         bool fork_recorded = false;
         if ((G.n_light && G.n_general && !light_const && G.light_overlap) || lds_helper)
