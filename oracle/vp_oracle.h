@@ -15,8 +15,16 @@
  *   - pinned since round 3 by an output the reference itself holds: the GEOMETRY chain -- FractalJuliaSet and its voxelisation,
  *     the volume box, the camera matrix, field of view and pixel-to-ray map, intersectBox -- by the silhouette of the reference's
  *     own screenshot of the Julia scene (/root/reference/2.jpg -> tests/golden/ref_julia_silhouette.npz, IoU 0.97 at the
- *     reference's default camera distance; tests/test_oracle_cpu.py).  Not its radiometry (the screenshot's environment is unknown).
- *   - everything else: "parity unpinned" -- a line-by-line restatement citing file:line.
+ *     reference's default camera distance; tests/test_oracle_cpu.py).
+ *   - pinned since round 4 by the same output, statistically: the RADIOMETRY of the integrator as a whole -- sun power x phase
+ *     function x albedo x transmittance x multiple scattering x display transform -- by the INTERIOR of that screenshot: per 16x16
+ *     block the luminance of this oracle's render of the fitted pose under the fitted sun (two parameters; exposure not fitted)
+ *     against the screenshot's, Pearson >= 0.98 (0.996 on the GPU at full resolution), absolute level within 13 %; the reference's
+ *     default medium and no other (g = 0, density 80, albedo 0.8 miss by 4-8x the residual).  tests/golden/ref_julia_interior.npz,
+ *     tests/test_oracle_cpu.py::test_julia_interior_matches_the_references_own_screenshot.  A block mean is thousands of paths:
+ *     it pins no single quirk.
+ *   - everything else -- the individual quirks Q4-Q9, the tex3D rule, bounds, opacity as such: "parity unpinned" -- a line-by-line
+ *     restatement citing file:line.
  */
 #ifndef VP_ORACLE_H
 #define VP_ORACLE_H
