@@ -642,6 +642,12 @@ static inline f3 frame_to_world(const frame_t* f, f3 c)
     return add3(add3(muls(f->t, c.x), muls(f->b, c.y)), muls(f->n, c.z));
 }
 
+/* WHAT-IF switches for the radiometric pin (tests/test_oracle_cpu.py::test_julia_interior_prefers_the_reference_as_read): the
+ * reference's own screenshot is compared with this restatement AND with variants in which one of its quirks is read differently.
+ * 0 = the restatement (everything else in tests/ and bench.py runs with 0).  bit 0: no "Hyperion" reduction (quirk Q9: s = 0);
+ * bit 1: Henyey-Greenstein sampling with cos(theta) clamped to [-1, 1] instead of [0, 1] (quirk Q1). */
+static int g_what_if = 0;
+void vpo_debug_set_what_if(int mask) { g_what_if = mask; }
 /* HGPhaseFunction::sample kernel.cu:580-598 (quirk Q1: cos_theta clamped to [0,1]) */
 static f3 hg_sample_local(float g, float rnd0, float rnd1)
 {
@@ -651,7 +657,7 @@ static f3 hg_sample_local(float g, float rnd0, float rnd1)
         float s   = 2.0f * rnd0 - 1.0f;
         float f   = (1.0f - g * g) / (1.0f + g * s);
         cos_theta = (0.5f / g) * (1.0f + g * g - f * f);
-        cos_theta = fmaxf(0.0f, fminf(1.0f, cos_theta));
+        cos_theta = fmaxf((g_what_if & 2) ? -1.0f : 0.0f, fminf(1.0f, cos_theta));
     }
     else
         cos_theta = 2.0f * rnd0 - 1.0f;
@@ -823,6 +829,7 @@ void vpo_default_camera(float m[12])
 /* hyperion trick kernel.cu:2039-2041 / :1358-1359 (quirk Q9) */
 static inline float hyperion_s(int n_minus)
 {
+    if (g_what_if & 1) return 0.0f;
     return fmaxf(0.0f, fminf(1.0f, (float)n_minus * 0.066666666666666666667f));
 }
 

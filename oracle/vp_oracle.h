@@ -21,9 +21,10 @@
  *     block the luminance of this oracle's render of the fitted pose under the fitted sun (two parameters; exposure not fitted)
  *     against the screenshot's, Pearson >= 0.98 (0.996 on the GPU at full resolution), absolute level within 13 %; the reference's
  *     default medium and no other (g = 0, density 80, albedo 0.8 miss by 4-8x the residual).  tests/golden/ref_julia_interior.npz,
- *     tests/test_oracle_cpu.py::test_julia_interior_matches_the_references_own_screenshot.  A block mean is thousands of paths:
- *     it pins no single quirk.
- *   - everything else -- the individual quirks Q4-Q9, the tex3D rule, bounds, opacity as such: "parity unpinned" -- a line-by-line
+ *     tests/test_oracle_cpu.py::test_julia_interior_matches_the_references_own_screenshot.  And the one quirk with a first-order
+ *     effect on that image, Q9 (the "Hyperion" reduction): the same fit WITHOUT it (vpo_debug_set_what_if) misses the screenshot by
+ *     more than twice the residual (test_julia_interior_prefers_the_reference_as_read).
+ *   - everything else -- the quirks Q4-Q8, the tex3D rule, bounds, opacity as such: "parity unpinned" -- a line-by-line
  *     restatement citing file:line.
  */
 #ifndef VP_ORACLE_H
@@ -121,6 +122,7 @@ float    vpo_sample_density(const vpo_scene* S, const float pos[3]);
 void     vpo_sample_bound(const vpo_scene* S, const float pos[3], float out_max_min[2]);
 float    vpo_sample_opacity(const vpo_scene* S, const float pos[3]);
 void     vpo_build_env_tables(const float* env, int width, int height, float* cdf_y, float* cdf_x, float* pdfnorm_alt);
+void     vpo_debug_set_what_if(int mask); /* test hook: variants of the restatement for the radiometric pin (0 = the restatement; vp_oracle.c) */
 uint64_t vpo_debug_shadow_overflow(void); /* test hook: shadow rays that drew more than the 2^20 pairs of their sub-stream (must stay 0) */
 uint64_t vpo_debug_mis_zero_pdf(void); /* test hook: zero-pdf `continue`s taken so far (kernel.cu:2266) */
 void     vpo_eval_envmap(const vpo_scene* S, const float dir[3], float rgb[3]);

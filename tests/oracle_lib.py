@@ -75,6 +75,7 @@ def lib():
         L.vpo_build_env_tables.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vpo_debug_mis_zero_pdf.restype = C.c_uint64
         L.vpo_debug_shadow_overflow.restype = C.c_uint64
+        L.vpo_debug_set_what_if.argtypes = [C.c_int]
         L.vpo_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float]
         L.vpo_gamma_correct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float]
         _LIB = L
