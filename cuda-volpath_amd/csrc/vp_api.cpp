@@ -130,7 +130,7 @@ struct State
     // the samples of the light class are per-pixel constants when a null collision in empty space leaves a throughput of 1
     // exactly 1 (light_identity_k): decided per (medium, estimator, volume), then miss_fill_k writes them
     bool        use_light_const = true;
-    unsigned*   d_appr_aux[3] = {nullptr, nullptr, nullptr};   // per render target (caller's stream, two look-ahead slots): LaunchDev::approach_aux
+    uint2*      d_appr_aux[3] = {nullptr, nullptr, nullptr};   // per render target (caller's stream, two look-ahead slots): LaunchDev::approach_aux
     size_t      appr_aux_bytes[3] = {0, 0, 0};
     int         last_approach = 0;            // vp_last_approach_mode
     int         last_light_const = 0;         // vp_last_light_const
@@ -921,13 +921,14 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     size_t max_f = (nframes > 1 || stage_only) ? stage_frames_cap(per_frame, *T.stage_bytes) : 1;
     SceneDev S = G.S;
     S.linear   = G.linear ? 1 : 0;
-    // sampler.h's state is two words and the staging slot of the decomposition estimator's hand-over holds the segment origin and one:
-    // the other goes beside it.  Sized ONCE, before the launch loop (no synchronisation, no early return between a launch's events).
-    const bool appr_aux_needed = approach && G.est == VP_EST_DECOMP && G.rng == VP_RNG_SAMPLERH && (nframes > 1 || stage_only);
+    // The staging slot of the decomposition estimator's hand-over holds the segment origin and the distance reached in it: the stream's
+    // state (a pair index, or sampler.h's two words) goes beside it.  Sized ONCE, before the launch loop (no synchronisation, no early
+    // return between a launch's events).
+    const bool appr_aux_needed = approach && G.est == VP_EST_DECOMP && (nframes > 1 || stage_only);
     if (appr_aux_needed)
     {
         const int    ti    = T.index;
-        const size_t need4 = per_frame * std::min<size_t>((size_t)nframes, max_f) * sizeof(unsigned);
+        const size_t need4 = per_frame * std::min<size_t>((size_t)nframes, max_f) * sizeof(uint2);
         if (need4 > G.appr_aux_bytes[ti])
         {
             HIPCHK(hipStreamSynchronize(T.stream));
@@ -980,7 +981,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         // (not for look-ahead batches: two of them overlap -- the next one's approach walk and first workgroups run beside the current
         // one's body and tail -- only if the current one leaves registers free: four LDS-table waves per SIMD do, the helper's fifth does
         // not.  C3 host loop 1301 -> 1510 Msamples/s without it, profiles/r03_render_kernel_lookahead.txt)
-        // COUPLING (two tuning decisions that depend on each other): approach_local_k needs 45 vector registers (kernel_resources.py);
+        // COUPLING (two tuning decisions that depend on each other): approach_local_k needs 47 vector registers (kernel_resources.py);
         // beside four 97-102-register LDS-table waves AND the helper's fifth 96-register wave a SIMD has 27 left, beside the four
         // alone 124.  If approach_local_k's register count or the helper's occupancy changes, re-measure the `!tgt` below.
         const bool lds_helper = lds_bounds && G.lds_helper && G.n_general && !(G.n_light && !light_const) && !tgt;
@@ -1714,8 +1715,8 @@ int vp_reserve_frames(const Param* p, int nframes)
     // what do_render would allocate for the first launch of such a job (a one-frame call accumulates directly and stages nothing)
     const size_t f    = std::min<size_t>((size_t)nframes, stage_frames_cap(sh.per_frame, G.stage_bytes));
     const size_t need = sh.per_frame * f * sizeof(float4);
-    // (sampler.h + decomposition estimator: the second word of the stream's state beside each staging slot, do_render)
-    const size_t need4 = (G.est == VP_EST_DECOMP && G.rng == VP_RNG_SAMPLERH && G.use_approach && G.use_approach_local) ? sh.per_frame * f * sizeof(unsigned) : 0;
+    // (decomposition estimator: the stream's state beside each staging slot of the approach kernel's hand-over, do_render)
+    const size_t need4 = (G.est == VP_EST_DECOMP && G.use_approach && G.use_approach_local) ? sh.per_frame * f * sizeof(uint2) : 0;
     if (need4 > G.appr_aux_bytes[0])
     {
         HIPCHK(hipStreamSynchronize(G.stream));

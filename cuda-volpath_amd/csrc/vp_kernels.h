@@ -103,7 +103,8 @@ struct LaunchDev
     // Counter-based streams: approach_k (global majorant) / approach_local_k (decomposition) has walked the camera ray of every sample
     // of this launch through its certified-empty stretch already and left (distance reached, draw pairs used) / (segment origin, pairs
     // used) in the sample's staging slot; the integrator takes a new sample up from there.  0 = start as the reference does.
-    unsigned* approach_aux;   // sampler.h + decomposition: the second word of the stream's state per staging slot (the slot holds four)
+    uint2*   approach_aux;    // decomposition estimator: the stream's state per staging slot (the slot holds the segment origin and the distance
+                              // reached in it): .x = pair index (counter-based) / sampler.h's two words
     unsigned approach;        // 1: the walk's null collisions leave the throughput at 1; 2 (global majorant): look it up by their number in thr_table
     unsigned approach_fshift; // log2 of the frames a wave of the approach kernels spans (6 where the launch has 64 frames or more)
     unsigned approach_steps;  // most free-flight steps (restart segments) the walk makes per sample (the integrator does what is left)

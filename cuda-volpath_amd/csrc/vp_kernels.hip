@@ -336,6 +336,7 @@ void render_k(SceneDev S, LaunchDev L)
         };
         auto next_segment = [&]() __attribute__((always_inline)) {
             st = ST_SETUP;
+            if (LOCAL) dist = -1.0f;
             if (EXITC) terms = L.exit_start;
             if (EST == EST_GLOBAL) nsc++;
             if (EST == EST_BOUNDED) seg++;
@@ -704,6 +705,7 @@ void render_k(SceneDev S, LaunchDev L)
                                 if (EXITC) terms = L.exit_start;
                                 if (COUNT) ex_clear = false;
                                 if (!LIGHT) t_empty = L.crawl ? L.crawl[2 * ((size_t)px + (size_t)py * P.width) + 1].x : 0.0f;
+                                if (LOCAL) dist = -1.0f;   // a segment starts where the ray enters it (segment_setup), unless approach_local_k got further
                                 if (APPR && L.approach)
                                 {
                                     const float4 a = L.stage[item];   // approach_k: distance reached, where the stream stands, steps made
@@ -744,11 +746,14 @@ void render_k(SceneDev S, LaunchDev L)
                                         // projection on the ray, a margin of 1e-4 against its rounding: a shorter certificate renders the
                                         // same bits, it only fetches a zero it could have skipped)
                                         const float4 a  = L.stage[item];
+                                        const uint2  ax = L.approach_aux[item];
                                         const f3     ra = f3{a.x, a.y, a.z};
                                         t_empty = t_empty - dot(ra - ro, rd) - 1e-4f;
                                         ro      = ra;
-                                        // where the stream stands: the pair index, or sampler.h's two words (the second beside the slot)
-                                        rng.load(f2u(a.w), RNG::kShadowSubstream ? 0u : L.approach_aux[item]);
+                                        // how far into the segment at ra the walk got (-1: not at all): the set-up below keeps it
+                                        dist    = a.w;
+                                        // where the stream stands: the pair index, or sampler.h's two words
+                                        rng.load(ax.x, ax.y);
                                     }
                                 }
                                 st  = ST_SETUP;
@@ -830,7 +835,9 @@ ends_done:
                 if (!hit) st = EV_BG;
                 else
                 {
-                    dist          = t_near;
+                    // (where the free flight of this segment starts: where the ray enters it -- or, in the one segment approach_local_k
+                    // handed over half-walked, where that walk got; every other set-up finds dist = -1)
+                    dist          = fmaxf(dist, t_near);
                     // phase_g and cur_density of this scatter count: segment_medium().  Scalar build: no local bound (:2063 / :1745)
                     sigma_t_prime = TRK ? cur_density : max_sig * cur_density * d_max;
                     inv_sigma_t   = 1.0f / sigma_t_prime;
@@ -892,7 +899,8 @@ ends_done:
             }
             else
             {
-                st = ST_SETUP;
+                st   = ST_SETUP;
+                dist = -1.0f;
                 if (EST == EST_BOUNDED) seg++;
                 if ((EST == EST_BOUNDED ? seg : nsc) >= 800) st = EV_WRITE;
                 float s         = hyperion_s(nsc - 5);
@@ -951,7 +959,8 @@ ends_done:
                         {
                             ro = ro + rd * t_far;  // tracking restart kernel.cu:2151-2155 / :1809-1813
                             t_empty -= t_far;      // the certified-empty distance is measured from the segment origin
-                            st = ST_SETUP;
+                            st   = ST_SETUP;
+                            dist = -1.0f;
                             if (EXITC) terms += d_max <= 0.0001f ? VP_EXIT_TRIP : 0;   // exit flights: a segment through a brick with maximum zero
                             if (EST == EST_BOUNDED && ++seg >= 800) st = EV_WRITE;  // `continue` still counts, :1716
                         }
@@ -1647,9 +1656,9 @@ __global__ __launch_bounds__(256) void approach_k(SceneDev S, LaunchDev L)
 // The same for the decomposition estimator (uchar bound table): behind the crawl in front of the box (crawl_table_k) the camera ray
 // walks restart segments of 0.05 through bricks whose cells it is certified not to meet non-empty (t_empty): a bound fetch, and free
 // flights with the brick's majorant whose null collisions change nothing (checked per segment), until the flight leaves the segment.  A thread per sample walks every segment that ENDS before the certified distance -- no fetch can
-// fall into it -- and hands over at the origin of the first one that does not (or whose brick has a positive minimum: the control
-// distance is the integrator's business): (origin, pairs used) in the sample's staging slot.  A segment it started and could not
-// finish is simply made again by render_k, from its start, with the same pairs.
+// fall into it -- and then INTO the first one that does not, up to the flight that would need a fetch (round 4): (origin of that
+// segment, distance reached in it) in the sample's staging slot, the stream's state beside it.  A segment whose brick has a positive
+// minimum (the control distance is the integrator's business) or a non-neutral majorant is handed over at its origin.
 template <class RNG, bool QUANT>
 __global__ __launch_bounds__(256) void approach_local_k(SceneDev S, LaunchDev L)
 {
@@ -1675,8 +1684,9 @@ __global__ __launch_bounds__(256) void approach_local_k(SceneDev S, LaunchDev L)
     RNG rng;
     rng.init(px, py, (unsigned)(L.frame0 + (int)fl), L.key0, L.key1);
     rng.skip(f2u(c.w) >> 16);   // the crawl's draws
-    unsigned sa, sb;            // where the stream stands at the origin of the segment in hand
+    unsigned sa, sb;            // where the stream stands: at the origin of the segment in hand, or before the flight it stopped at
     rng.save(sa, sb);
+    float    d_reached = -1.0f; // how far into the segment at `ro` the walk got (free-flight distance from its origin); -1: not at all
     unsigned long long n_steps = 0, n_segs = 0;
     for (unsigned n = 0; n < L.approach_steps; n++)
     {
@@ -1697,6 +1707,7 @@ __global__ __launch_bounds__(256) void approach_local_k(SceneDev S, LaunchDev L)
         float    dist = t_near;
         unsigned steps = 0;
         bool     through = false;
+        unsigned ta = sa, tb = sb;   // the stream before the flight in hand
         for (;;)
         {
             const float d2 = dist + -logf_(rng.next_a()) * inv_sigma;   // kernel.cu:2085
@@ -1704,18 +1715,26 @@ __global__ __launch_bounds__(256) void approach_local_k(SceneDev S, LaunchDev L)
             if (!(d2 < t_empty) || steps > 60000u) break;                 // a fetch: render_k's
             dist = d2;
             (void)rng.next_b();   // the collision test's variate (`real` is false whatever it is): a sequential stream moves past it
+            rng.save(ta, tb);
             steps++;
         }
-        if (!through) break;      // (the stream's state at the origin of this segment is what is handed over)
-        rng.save(sa, sb);
         n_steps += steps;
+        if (!through)
+        {
+            // the flight in hand needs a fetch: render_k takes the path up INSIDE this segment -- its own set-up of the segment at `ro`
+            // (the same bound, majorant and t_far), then the flight from `dist` with the stream as it stood before that flight
+            // (round 4; before, the whole segment was handed back and walked again, ~38 steps per path of the decomposition workloads)
+            d_reached = dist; sa = ta; sb = tb;
+            break;
+        }
+        rng.save(sa, sb);
         n_segs++;
         ro      = ro + rd * t_far;   // tracking restart kernel.cu:2151-2155
         t_empty -= t_far;
     }
     const size_t item = (size_t)fl * L.stage_stride + L.slot_base + slot;
-    L.stage[item] = make_float4(ro.x, ro.y, ro.z, u2f(sa));
-    if (!RNG::kShadowSubstream) L.approach_aux[item] = sb;   // sampler.h: the second word of its state
+    L.stage[item] = make_float4(ro.x, ro.y, ro.z, d_reached);
+    L.approach_aux[item] = make_uint2(sa, sb);   // where the stream stands: the pair index, or sampler.h's two words
     if (L.counters)
     {
         if (n_steps) atomicAdd(&L.counters[1], n_steps);   // density lookups and bound lookups the estimator makes on this stretch
