@@ -52,7 +52,9 @@ struct SceneDev
     const float*         cells_f32;  // float volume: the same neighbourhood as 8 floats
     const unsigned char* bounds_u8;  // (max,min) byte pairs per brick
     const float*         bounds_f32; // (max,min) float pairs per brick
-    const float*         opacity;    // optical depth toward the sun, N^3 floats (or null)
+    const float*         opacity;    // optical depth toward the sun, N^3 floats (or null): what precompute_opacity computes (vp_get_opacity)
+    const float*         opacity_cells;  // ... the same values as per-voxel 2x2x2 neighbourhood cells of 8 floats (pack_cells_f32_k): what
+                                     // the integrator reads -- one 32-byte cell instead of eight scattered floats (four cache lines)
     const float4*        env;        // lat-long environment, row 0 = zenith
     int   nx, ny, nz, linear;
     int   cell_bricks;   // layout of the packed cells: 0 = x fastest over the whole grid; 1 = 4x4x4 bricks of 64 cells (512 B of uchar
@@ -330,6 +332,34 @@ __device__ __forceinline__ float sample_float_volume(const SceneDev& S, const fl
     float y0  = lerpf(x00, x10, w[1]);
     float y1  = lerpf(x01, x11, w[1]);
     return lerpf(y0, y1, w[2]);
+}
+
+// The same fetch from the neighbourhood-packed copy of the table (SceneDev::opacity_cells): the cell of voxel (i, j, k) holds the
+// clamped taps (i..i+1, j..j+1, k..k+1), so the eight loads above become two 16-byte loads of one line.  Same taps, same weights, same
+// order of the lerps: the same bits.  Below the first texel centre of an axis both taps are texel 0 (a[ax] = b[ax] = 0 above): the
+// cell of voxel 0 holds texels 0 and 1, so its first tap is used twice, as in sample_density01's float path.
+__device__ __forceinline__ float sample_float_cells(const SceneDev& S, const float* cells, f3 pos)
+{
+    f3    p = to_local(S, pos);
+    int   i, j, k;
+    float fx, fy, fz;
+    bool  lx, ly, lz;
+    axis_linear_f32(p.x, S.nx, i, fx, lx);
+    axis_linear_f32(p.y, S.ny, j, fy, ly);
+    axis_linear_f32(p.z, S.nz, k, fz, lz);
+    const size_t  idx = (size_t)((unsigned)i + __umul24((unsigned)S.nx, (unsigned)j + __umul24((unsigned)S.ny, (unsigned)k)));
+    const float4* q   = reinterpret_cast<const float4*>(cells) + idx * 2;
+    float4        lo = q[0], hi = q[1];
+    if (lx) { lo.y = lo.x; lo.w = lo.z; hi.y = hi.x; hi.w = hi.z; }
+    if (ly) { lo.z = lo.x; lo.w = lo.y; hi.z = hi.x; hi.w = hi.y; }
+    if (lz) hi = lo;
+    float x00 = lerpf(lo.x, lo.y, fx);
+    float x10 = lerpf(lo.z, lo.w, fx);
+    float x01 = lerpf(hi.x, hi.y, fx);
+    float x11 = lerpf(hi.z, hi.w, fx);
+    float y0  = lerpf(x00, x10, fy);
+    float y1  = lerpf(x01, x11, fy);
+    return lerpf(y0, y1, fz);
 }
 
 // point-sampled (max,min) bound of the brick containing pos: vol_bound_minmax kernel.cu:1610-1624

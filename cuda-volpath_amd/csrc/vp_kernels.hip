@@ -399,7 +399,7 @@ void render_k(SceneDev S, LaunchDev L)
             if (EST == EST_DECOMP && frame > 10 && nsc > 20)
             {
                 // precomputed optical depth kernel.cu:2183-2189 (quirk Q5)
-                float op = sample_float_volume(S, S.opacity, ro);
+                float op = sample_float_cells(S, S.opacity_cells, ro);   // = sample_float_volume(S, S.opacity, ro), from one line
                 if (COUNT) c_opa++;
                 if (TRK)
                 {
