@@ -143,6 +143,7 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
     import torch.distributed as dist
     import volpath as vp
     from volpath import scene as vscene
+    from volpath import dist as vdist
     rank, world, dev, stream, rehearsal = ctx["rank"], ctx["world"], ctx["dev"], ctx["stream"], ctx["rehearsal"]
     rng = rng or args.rng
     spp_step = spp_per_gpu * world if scaling == "weak" else spp_per_gpu
@@ -196,14 +197,9 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
                 # this rank's contiguous share of the step's frames, all pixels; partial images gathered and added in rank order
                 share = spp // world
                 vp.render_frames(acc.data_ptr(), first + rank * share, share, P)
-                part = acc.cpu() if rehearsal else acc
-                parts = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
-                dist.gather(part, parts, dst=0)
+                total = vdist.gather_sum_in_rank_order(acc.cpu() if rehearsal else acc, dst=0)
                 if rank == 0:
-                    total = parts[0].to(dev)
-                    for q in parts[1:]:
-                        total = total + q.to(dev)
-                    image.add_(total)
+                    image.add_(total.to(dev))
                 return
             vp.render_frames(acc.data_ptr(), first, spp, P)
             if world > 1 and rehearsal:

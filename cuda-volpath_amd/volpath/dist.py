@@ -60,3 +60,23 @@ def reduce_accumulator(acc, dst=0, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return acc
+
+
+def gather_sum_in_rank_order(part, dst=0, group=None):
+    """The frame split of a fixed job (bench.py --split frames): every rank holds a partial image of ALL pixels
+    (its share of the frames); rank `dst` gathers them and returns ((p0 + p1) + p2) + ... -- a defined result, because binary32
+    addition does not associate (a reduce would add in the library's order).  Other ranks return None."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if world == 1:
+        return part
+    rank = dist.get_rank(group)
+    parts = [torch.empty_like(part) for _ in range(world)] if rank == dst else None
+    dist.gather(part, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    total = parts[0].clone()
+    for q in parts[1:]:
+        total = total + q
+    return total

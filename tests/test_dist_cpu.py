@@ -104,3 +104,47 @@ def test_two_rank_reduce_is_bit_identical():
     for p in procs:
         p.join(timeout=60)
     assert ok
+
+
+def _worker_frames(rank, world, port, q):
+    import sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-volpath_amd"))
+    from volpath import dist as vd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # partial images of very different magnitudes: the order of the additions shows in the bits
+    parts = [np.random.default_rng(5 + r).random((48, 64, 4), dtype=np.float32) * np.float32(10.0 ** (3 * r)) for r in range(world)]
+    total = vd.gather_sum_in_rank_order(torch.from_numpy(parts[rank].copy()), dst=0)
+    if rank == 0:
+        want = parts[0].copy()
+        for p in parts[1:]:
+            want = want + p
+        other = parts[-1].copy()
+        for p in parts[-2::-1]:
+            other = other + p
+        q.put((bool(np.array_equal(total.numpy(), want)), bool(np.array_equal(want, other))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_split_adds_partial_images_in_rank_order():
+    """bench.py --split frames over gloo, three ranks: rank 0 gets ((p0 + p1) + p2) bit for bit -- and that is not the sum in the
+    opposite order, which is why the order is part of the definition."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_frames, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    same, order_free = q.get(timeout=90)
+    for p in procs:
+        p.join(timeout=60)
+    assert same and not order_free
