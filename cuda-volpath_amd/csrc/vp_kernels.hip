@@ -15,6 +15,9 @@
 // approach_k / approach_local_k: in staged launches the remaining pixels' camera rays are walked through their certified-empty
 // stretch -- draw, logarithm, add, compare -- by a thread per sample ahead of render_k, which takes each path up from its
 // staging slot: work sorted by kind across the chip instead of lanes waiting beside lanes that fetch.
+// Exit flights (round 4): a path in empty space that can meet empty cells only on its way out of the box (a per-cell table of 24
+// direction classes, exit_dir_slice_k) and whose null collision multiplies its throughput by exactly 1.0f ends with the environment
+// whatever it draws -- it is ended at once, tested for free-riding lanes whenever their wave is in the event pass anyway.
 // Restates
 //   __d_render_bounded_decomp  kernel.cu:1958-2318  (EST_DECOMP, the reference's live kernel)
 //   __d_render                 kernel.cu:1285-1591  (EST_GLOBAL, BASELINE config 2)
