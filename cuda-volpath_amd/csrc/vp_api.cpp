@@ -89,8 +89,9 @@ struct State
     unsigned long long* d_counters = nullptr;
     bool        count       = false;
     unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS, setup_lanes = VP_SETUP_LANES, end_lanes = VP_END_LANES, light_wait_iters = 0;  // 0 = by estimator
-    unsigned    blocks_per_cu = 5;  // resident 256-thread workgroups per CU of a kernel that runs alone (the general kernels hold 94-96 vector
-                                    // registers: five waves per SIMD)
+    unsigned    blocks_per_cu = 8;  // 256-thread workgroups per CU launched for a kernel that runs alone: as many as can be resident (seven of
+                                    // the achromatic global-majorant kernel, six of the other plain ones, five of the chromatic local ones; a
+                                    // workgroup too many starts when the queues are empty and ends at once)
     unsigned    chunk_fshift = 0;         // VP_CHUNK_FRAMES_LOG2: a chunk = (256 >> k) pixels x (1 << k) frames (general class)
     bool        use_lds_bounds = true;
     bool        lds_helper  = true;       // one plain workgroup per CU beside the LDS-table kernel (VP_NO_LDS_HELPER=1)
@@ -1033,6 +1034,9 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             if (both && cls) bpc = G.light_blocks_per_cu ? G.light_blocks_per_cu : (G.est == VP_EST_GLOBAL ? 2u : 6u);
             if (!both && cls) bpc = 8u;   // the light kernel alone: 64 registers
             if (both && !cls) bpc = G.general_blocks_per_cu ? G.general_blocks_per_cu : (G.est == VP_EST_GLOBAL ? 4u : 5u);
+            // look-ahead batches overlap in pairs: the next batch's approach walk (23 / 47 registers) must find room beside the current
+            // batch's integrator -- six of its 72-register workgroups leave 80 registers per SIMD lane, five 80-register ones 112
+            if (tgt && !cls && !both) bpc = std::min(bpc, G.est == VP_EST_GLOBAL ? 6u : 5u);
             unsigned cap    = (unsigned)G.num_cu * (ldsb ? 2u : bpc);
             if (blocks > cap) blocks = cap;
             // the light kernel's paths are long and end rarely: its waves leave the tracking loop for the (refill / environment /

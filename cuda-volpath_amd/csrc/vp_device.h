@@ -110,8 +110,8 @@ struct RngSamplerH
     __device__ __forceinline__ void skip(unsigned n) { for (unsigned i = 0; i < n; i++) word(); }
     // the reference's stream is sequential: a shadow ray draws from it like everything else
     static constexpr bool kShadowSubstream = false;
-    __device__ __forceinline__ void enter_shadow(unsigned) {}
-    __device__ __forceinline__ void leave_shadow() {}
+    __device__ __forceinline__ unsigned enter_shadow(unsigned) { return 0u; }
+    __device__ __forceinline__ void leave_shadow(unsigned) {}
     __device__ __forceinline__ void set_pair(unsigned) {}
     // where the stream stands, in two words (approach_k hands a path over to render_k)
     __device__ __forceinline__ void save(unsigned& a, unsigned& b) const { a = sx; b = sy; }
@@ -130,7 +130,7 @@ struct RngPhiloxR
     unsigned w1;              // second word of the current pair
     __device__ __forceinline__ void init(unsigned px, unsigned py, unsigned frame, unsigned key0, unsigned key1)
     {
-        pix = (px << 16) | py; key = (frame ^ key0) + key1; pair = 0; w1 = 0; saved = 0;
+        pix = (px << 16) | py; key = (frame ^ key0) + key1; pair = 0; w1 = 0;
     }
     __device__ __forceinline__ float next_a()
     {
@@ -156,9 +156,9 @@ struct RngPhiloxR
     // afterwards where it stood (oracle: rng_enter_shadow).  What the path draws after a light estimate then does not depend
     // on the number of steps the estimate took, so a shadow ray may stop as soon as nothing can change its result any more.
     static constexpr bool kShadowSubstream = true;
-    unsigned saved;
-    __device__ __forceinline__ void enter_shadow(unsigned id) { saved = pair; pair = 0x80000000u + (id << 20); }
-    __device__ __forceinline__ void leave_shadow() { pair = saved; }
+    // (the caller keeps the position of the path's own stream while the shadow ray draws: cold state, render_k)
+    __device__ __forceinline__ unsigned enter_shadow(unsigned id) { const unsigned saved = pair; pair = 0x80000000u + (id << 20); return saved; }
+    __device__ __forceinline__ void leave_shadow(unsigned saved) { pair = saved; }
     // take the stream up at pair index n (approach_k has consumed the pairs before it)
     __device__ __forceinline__ void set_pair(unsigned n) { pair = n; }
     __device__ __forceinline__ void save(unsigned& a, unsigned& b) const { a = pair; b = 0u; }

@@ -40,8 +40,9 @@
 #define VP_LIGHT_MIN_WAVES 8   // the light kernels fit 64 vector registers: two of their waves beside four of a 96-register kernel
 #endif
 #ifndef VP_GLOBAL_MIN_WAVES
-#define VP_GLOBAL_MIN_WAVES 5  // achromatic global-majorant kernel: waves per SIMD its register budget is held to (six cost three
-                               // spilled registers since the collision block also samples the phase function: 1190 vs 1341 Msamples/s on C2)
+#define VP_GLOBAL_MIN_WAVES 6  // achromatic global-majorant kernel: waves per SIMD its register budget is held to.  Six since the cold
+                               // per-path state lives in LDS (round 4: 79 registers, no spill); with that state in registers six cost
+                               // three spilled registers and lost to five (1190 vs 1341 Msamples/s on C2, round 3)
 #endif
 #ifndef VP_LIGHT_LOCAL_MIN_WAVES
 #define VP_LIGHT_LOCAL_MIN_WAVES 7   // the local-majorant light kernels need 66-68 registers with the Philox2x32-10 and sampler.h streams:

@@ -56,6 +56,49 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+// Cold per-path state (round 4).  A path's radiance sum, the direction it resumes after a shadow ray, its sample
+// coordinates, scatter count, phase-function parameters and the stream position saved across a shadow ray are touched in the event
+// blocks and where a shadow ray ends -- never in the free-flight step.  In the plain kernels they live in LDS, one word per lane
+// and field (14 words: 14 KB per workgroup), so that the kernel fits SIX waves per SIMD (80 registers) where it held five:
+// +4 % on both estimators (profiles/experiments/r04_cold_state_in_lds.txt).  ColdVal / ColdF3 are that word or triple in LDS
+// (COLD = true) or an ordinary variable (the LDS-table kernel, whose LDS is the table's, and the light kernels, which fit seven
+// or eight waves as they are).
+template <class T, bool COLD>
+struct ColdVal;
+template <class T>
+struct ColdVal<T, true>
+{
+    T* p;
+    __device__ __forceinline__ explicit ColdVal(float* q) : p(reinterpret_cast<T*>(q)) {}
+    __device__ __forceinline__ operator T() const { return *p; }
+    __device__ __forceinline__ ColdVal& operator=(T v) { *p = v; return *this; }
+};
+template <class T>
+struct ColdVal<T, false>
+{
+    T v = T();
+    __device__ __forceinline__ explicit ColdVal(float*) {}
+    __device__ __forceinline__ operator T() const { return v; }
+    __device__ __forceinline__ ColdVal& operator=(T w) { v = w; return *this; }
+};
+template <bool COLD, int STRIDE>
+struct ColdF3;
+template <int STRIDE>
+struct ColdF3<true, STRIDE>
+{
+    float* p;
+    __device__ __forceinline__ explicit ColdF3(float* q) : p(q) {}
+    __device__ __forceinline__ operator f3() const { return f3{p[0], p[STRIDE], p[2 * STRIDE]}; }
+    __device__ __forceinline__ ColdF3& operator=(f3 v) { p[0] = v.x; p[STRIDE] = v.y; p[2 * STRIDE] = v.z; return *this; }
+};
+template <int STRIDE>
+struct ColdF3<false, STRIDE>
+{
+    f3 v = {};
+    __device__ __forceinline__ explicit ColdF3(float*) {}
+    __device__ __forceinline__ operator f3() const { return v; }
+    __device__ __forceinline__ ColdF3& operator=(f3 w) { v = w; return *this; }
+};
 // One null collision of the spectral tracker where the density is +0 (kernel.cu:2107-2134 with sigma_t_den = +0: Ps = +0, c = Pn,
 // `real` false for any draw, sigma_null_den = sigma_t'), for a throughput with three equal channels t:
 // Pn = (m + m) + m with m = |sigma_t' t|, t *= sigma_t' * ((inv_sigma_t * Pn) / Pn).  The factor is 1 up to rounding, not exactly.
@@ -155,13 +198,19 @@ __global__ void light_identity_k(ParamDev P, int local, const unsigned* mask, un
 // meets certified-empty cells over its whole chord (empty_table_k / crawl_table_k), so a path is: restart segments (local-majorant
 // estimators) and free-flight steps whose null collisions have den = +0, then the environment.  No fetch code, no collision,
 // shadow or phase states.
+#ifndef VP_LOCAL_MIN_WAVES
+#define VP_LOCAL_MIN_WAVES 6   // plain achromatic local-majorant kernels, cold state in LDS: 80 registers, no spill.  The chromatic ones would
+                               // spill four or five at six waves and run as the LDS-table kernel's helper workgroups, where a fifth wave is
+                               // all a SIMD has room for: they keep five
+#endif
 template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool MIS, int TRK, bool LIGHT = false>
-// The local-majorant kernels need 98 VGPRs when left alone, two more than five waves per SIMD allow (512 / 5 -> 96):
-// asking for five costs no spill and is +10 % on the reference-table decomposition workload.  The global-majorant
-// kernel runs five as well (88 registers): six (80) cost three spilled registers since its collision block also samples the
-// phase function and prepares the next segment (1190 vs 1341 Msamples/s on C2); profiles/r03_kernel_resources.txt.
+// Occupancy (round 4: the cold per-path state in LDS, ColdVal above; profiles/r04_kernel_resources.txt).  The achromatic
+// global-majorant kernel needs 72 registers: SEVEN waves per SIMD (C2 2541 -> 2781 Msamples/s); the chromatic one and the plain
+// achromatic local-majorant kernels 80: six (c3ref 2398 -> 2513); the LDS-table kernel keeps its state in registers (its LDS is the
+// table's): 98, four waves and the helper workgroup's fifth.  Before, with everything in registers: 91-96, five waves (six cost
+// three spilled registers and lost).
 __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK,
-                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : (EST != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES)) : MIS || LDSB ? 1 : (EST == EST_GLOBAL && ACH && TRK == 0 ? VP_GLOBAL_MIN_WAVES : (TRK ? 4 : 5))))
+                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : (EST != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES)) : MIS || LDSB ? 1 : (EST == EST_GLOBAL && TRK == 0 ? VP_GLOBAL_MIN_WAVES : (TRK ? 4 : (ACH ? VP_LOCAL_MIN_WAVES : 5)))))
 void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
@@ -205,19 +254,27 @@ void render_k(SceneDev S, LaunchDev L)
     // ---- per-lane path state
     int      st = ST_DONE;
     bool     exhausted = false;
-    unsigned item = 0;           // where this lane's sample goes in the staging buffer
-    unsigned px = 0, py = 0;
-    int      frame = 0;
+    // cold state: in LDS for the plain kernels (ColdVal / ColdF3 above)
+    constexpr bool COLD = !LDSB && !LIGHT;
+    constexpr int  CS_  = COLD ? VP_BLOCK : 1;
+    __shared__ float cold_[COLD ? 14 : 1][CS_];
+    float* const cold_p = &cold_[0][COLD ? threadIdx.x : 0];
+    ColdF3<COLD, CS_>       rad(cold_p), pd(cold_p + 3 * CS_);   // radiance sum; primary direction, kept while the shadow ray is tracked
+    ColdVal<float, COLD>    ph(cold_p + 6 * CS_), phase_g(cold_p + 7 * CS_);
+    ColdVal<unsigned, COLD> item(cold_p + 8 * CS_);              // where this lane's sample goes in the staging buffer
+    ColdVal<unsigned, COLD> px(cold_p + 9 * CS_), py(cold_p + 10 * CS_);
+    ColdVal<int, COLD>      frame(cold_p + 11 * CS_);
+    ColdVal<int, COLD>      nsc(cold_p + 12 * CS_);              // num_scatters (DECOMP, BOUNDED) / depth i (GLOBAL)
+    ColdVal<unsigned, COLD> rng_saved(cold_p + 13 * CS_);        // the path's own stream position while a shadow ray draws from its sub-stream
+    if (COLD) { rad = f3{0.0f, 0.0f, 0.0f}; pd = f3{0.0f, 0.0f, 0.0f}; ph = 0.0f; phase_g = 0.0f; item = 0u; px = 0u; py = 0u; frame = 0; nsc = 0; rng_saved = 0u; }
     RNG      rng;
     f3       ro = {}, rd = {};   // the ray being tracked (primary, or the shadow ray while ST_SHADOW)
-    f3       pd = {};            // primary direction, kept while the shadow ray is tracked
     f3       inv_rd = {};        // 1 / rd of the primary ray (decomposition set-up)
-    f3       thr = {}, rad = {};
-    int      nsc = 0;            // num_scatters (DECOMP, BOUNDED) / depth i (GLOBAL)
+    f3       thr = {};
     int      seg = 0;            // BOUNDED only: loop index i, one per tracked segment (kernel.cu:1716)
     float    dist = 0, t_end = 0;  // position on the tracked ray; where the current free flight ends
     float    t_far = 0, distc = 0, inv_sigma = 0, inv_sigma_t = 0, sigma_t_prime = 0, sigma_c = 0;
-    float    cur_density = 0, d_max = 0, phase_g = 0, ph = 0;
+    float    cur_density = 0, d_max = 0;
     f3       nee_a = {};
     int      terms = 0;
     // MIS only: colour and weight of the light estimate in flight, rad += nee_c * (nee_t * transmittance);
@@ -302,7 +359,7 @@ void render_k(SceneDev S, LaunchDev L)
                 inv_sigma   = inv_s;
                 cur_density = den;
                 st          = ST_SHADOW;
-                rng.enter_shadow(2u * (unsigned)nsc + stage);
+                rng_saved = rng.enter_shadow(2u * (unsigned)(int)nsc + stage);
                 if (COUNT) t_clip = 1e30f;
                 if (RNG::kShadowSubstream && stage == 0u && L.sun_clip)
                 {
@@ -341,7 +398,7 @@ void render_k(SceneDev S, LaunchDev L)
             st = ST_SETUP;
             if (LOCAL) dist = -1.0f;
             if (EXITC) terms = L.exit_start;
-            if (EST == EST_GLOBAL) nsc++;
+            if (EST == EST_GLOBAL) nsc = nsc + 1;
             if (EST == EST_BOUNDED) seg++;
             if ((EST == EST_BOUNDED ? seg : nsc) >= 800) st = EV_WRITE;
             segment_medium();
@@ -358,7 +415,7 @@ void render_k(SceneDev S, LaunchDev L)
         {
             if (COUNT) { c_sca++; zrun = 0; }
             t_empty = 0.0f;  // the certificate is for the unscattered camera ray only
-            if (LOCAL) nsc++;  // num_scatters += !through, kernel.cu:2146
+            if (LOCAL) nsc = nsc + 1;  // num_scatters += !through, kernel.cu:2146
             // "to match passive result": post-increment count (DECOMP :2168) / i-4 (GLOBAL :1465)
             float s2 = hyperion_s((LOCAL) ? (nsc - 5) : (nsc - 4));
             float dp2, stp2;
@@ -388,7 +445,7 @@ void render_k(SceneDev S, LaunchDev L)
                 float r0 = rng.next_a();
                 float r1 = rng.next_b();
                 pd       = normalize(fr.to_world(hg_sample_local(phase_g, r0, r1)));
-                if (LOCAL) inv_rd = f3{1.0f / pd.x, 1.0f / pd.y, 1.0f / pd.z};
+                if (LOCAL) { const f3 pdv = pd; inv_rd = f3{1.0f / pdv.x, 1.0f / pdv.y, 1.0f / pdv.z}; }
             }
             if (MIS)
             {
@@ -874,7 +931,7 @@ ends_done:
             if (EXITC) terms = reinterpret_cast<const LaunchDev*>(ka_ + ((sizeof(SceneDev) + alignof(LaunchDev) - 1) / alignof(LaunchDev)) * alignof(LaunchDev))->exit_start;
             if (EST == EST_GLOBAL)
             {
-                nsc++;
+                nsc = nsc + 1;
                 if (nsc >= 800) st = EV_WRITE;
                 else if (t_far < 0.0f) { st = EV_BG; t_empty = 0.0f; }
                 else
@@ -952,7 +1009,7 @@ ends_done:
                         // Tr_spectral returns 1 - terminated flags (kernel.cu:807)
                         nee_a = f3{(float)(1 - (terms & 1)), (float)(1 - ((terms >> 1) & 1)), (float)(1 - ((terms >> 2) & 1))};
                         st    = EV_NEE;
-                        rng.leave_shadow();
+                        rng.leave_shadow(rng_saved);
                         if (EARLY) light_done();
                     }
                     else if (LOCAL)
@@ -1016,7 +1073,7 @@ ends_done:
                         // scalar delta tracking: kernel.cu:2137-2142 / :745-748 (Tr stops AT its collision, no further draw)
                         if (e < den * inv_sigma)
                         {
-                            if (shadow) { nee_a = f3{0.0f, 0.0f, 0.0f}; st = EV_NEE; rng.leave_shadow(); if (EARLY) light_done(); }
+                            if (shadow) { nee_a = f3{0.0f, 0.0f, 0.0f}; st = EV_NEE; rng.leave_shadow(rng_saved); if (EARLY) light_done(); }
                             else { ro = p; st = EV_SCATTER; }
                         }
                     }
