@@ -15,6 +15,7 @@
 #include <cstring>
 #include <deque>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/volpath.h"
@@ -49,7 +50,14 @@ struct State
     int         env_w = 0, env_h = 0;
     // frame look-ahead of render_kernel (see serve_frame): what the staged frames were rendered with
     unsigned long long epoch = 0;     // bumped whenever device CONTENT changes behind unchanged pointers
-    int         la_max      = 64;     // most frames rendered ahead per launch; <= 1 switches the look-ahead off
+    int         la_max      = 256;    // most frames rendered ahead per launch; <= 1 switches the look-ahead off
+    int         la_floor    = 64;     // batches up to this size are used from the start of a run; larger ones once the run is twice as long (VP_LOOKAHEAD_FLOOR)
+    bool        la_habit    = false;  // the caller has been served a staged frame: it asks for consecutive frames
+    bool        la_speculate = true;  // ... then the first batch of a run is queued beside the run's first frame (VP_LOOKAHEAD_NO_SPECULATION=1: behind it)
+    int         la_div      = 2;      // ... as long as la_div times the batch (VP_LOOKAHEAD_DIV)
+    int         la_run_first = 0;     // first frame of the current run of consecutive render_kernel calls
+    int         la_ramp_from = 8;     // size of the first batch of a run (VP_LOOKAHEAD_RAMP_FROM)
+    int         la_overlap_from = 2;  // a batch of at least this many frames has its successor queued behind it on the other slot (VP_LOOKAHEAD_OVERLAP_FROM)
     struct LaSlot  // one staged batch of frames, rendered on its own stream so that two batches overlap
     {
         float4*     buf = nullptr;
@@ -57,12 +65,16 @@ struct State
         hipStream_t stream = nullptr;
         hipEvent_t  done = nullptr;   // recorded after the batch's render
         bool        valid = false;
+        unsigned    cancel_seq = 0;   // the number of the batch of this slot that was last told to stop (la_cancel_running)
         bool        touched = false;  // a frame of this batch was handed to the caller while the batch was still running: its add-kernel
                                       // waits for the WHOLE batch, which must then run to its end (la_quiesce does not cancel it)
         int         first = 0, count = 0;
         std::vector<unsigned char> key;
     } la[2];
-    hipStream_t ctrl_stream = nullptr; // la_quiesce: tells batches in flight to stop handing out samples
+    // la_quiesce tells batches in flight to stop handing out samples: a stream of the HIGHEST priority -- such streams have hardware
+    // queues of their own; on an ordinary stream the write shared a queue with the very batch it was to stop and arrived when that
+    // batch had finished (3-22 ms later: profiles/experiments/r04_lookahead_cancel.txt)
+    hipStream_t ctrl_stream = nullptr;
     unsigned*   d_cancel    = nullptr; // [3] per render target: the newest batch number of the slot that is cancelled (LaunchDev::cancel)
     unsigned    batch_seq[3] = {0, 0, 0};   // number of the last batch queued on each target
     bool        la_cancel   = true;    // VP_NO_LA_CANCEL=1: batches in flight always run to their end
@@ -136,6 +148,7 @@ struct State
     size_t      appr_aux_bytes[3] = {0, 0, 0};
     int         last_approach = 0;            // vp_last_approach_mode
     int         last_light_const = 0;         // vp_last_light_const
+    unsigned    la_launched = 0, la_cancelled = 0;   // vp_lookahead_stats
     bool        use_approach_local = true;    // ... and approach_local_k ahead of the decomposition estimator (VP_NO_APPROACH_LOCAL=1: off)
     bool        use_approach = true;          // approach_k ahead of the global-majorant integrator (VP_NO_APPROACH=1: off)
     unsigned    approach_fshift_max = 6;      // a wave of the approach kernels = one pixel x 2^6 frames (VP_APPROACH_FRAMES_LOG2: 0 = 64 pixels of one frame)
@@ -280,6 +293,11 @@ int ensure_device()
     if (knob("VP_LIGHT_BLOCKS_PER_CU", 1, 8, v)) G.light_blocks_per_cu = (unsigned)v;
     if (knob("VP_THR_TABLE", 2, 1 << 20, v)) G.thr_entries = (unsigned)v;
     if (knob("VP_LOOKAHEAD", 0, 4096, v)) G.la_max = (int)v;
+    if (knob("VP_LOOKAHEAD_OVERLAP_FROM", 1, 4096, v)) G.la_overlap_from = (int)v;
+    if (knob("VP_LOOKAHEAD_RAMP_FROM", 2, 4096, v)) G.la_ramp_from = (int)v;
+    if (knob("VP_LOOKAHEAD_FLOOR", 1, 4096, v)) G.la_floor = (int)v;
+    if (knob("VP_LOOKAHEAD_DIV", 1, 16, v)) G.la_div = (int)v;
+    if (knob("VP_LOOKAHEAD_NO_SPECULATION", 0, 1, v)) G.la_speculate = v == 0;
     if (knob("VP_NO_LA_CANCEL", 0, 1, v)) G.la_cancel = v == 0;
     if (knob("VP_NO_EXIT", 0, 1, v)) G.use_exit = v == 0;
     if (knob("VP_EXIT_LOCAL", 0, 1, v)) G.exit_local = v != 0;
@@ -938,8 +956,11 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     if (appr_aux_needed)
     {
         const int    ti    = T.index;
-        const size_t need4 = per_frame * std::min<size_t>((size_t)nframes, max_f) * sizeof(uint2);
-        if (need4 > G.appr_aux_bytes[ti])
+        // (a look-ahead slot is sized for the largest batch at once: a slot that grew with every doubling of the ramp would
+        // synchronise its stream -- and the batch running beside it -- at every step)
+        const size_t fr4   = stage_only ? std::max<size_t>((size_t)nframes, (size_t)std::max(G.la_max, 1)) : (size_t)nframes;
+        const size_t need4 = per_frame * std::min<size_t>(fr4, max_f) * sizeof(uint2);
+        if (per_frame * std::min<size_t>((size_t)nframes, max_f) * sizeof(uint2) > G.appr_aux_bytes[ti])
         {
             HIPCHK(hipStreamSynchronize(T.stream));
             if (G.d_appr_aux[ti]) HIPCHK(hipFree(G.d_appr_aux[ti]));
@@ -959,11 +980,17 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             size_t need = per_frame * (size_t)f * sizeof(float4);
             if (need > *T.stage_bytes)
             {
+                // (a look-ahead slot is sized for the largest batch at once: growing with every doubling of the ramp would synchronise
+                // its stream, and the batch running beside it, at every step)
+                const size_t exact = need;
+                if (stage_only) need = per_frame * std::min<size_t>(std::max<size_t>((size_t)f, (size_t)std::max(G.la_max, 1)), max_f) * sizeof(float4);
                 HIPCHK(hipStreamSynchronize(T.stream));
                 HIPCHK(hipStreamSynchronize(G.stream));  // add-kernels of earlier frames may still read the old buffer
                 if (*T.stage) HIPCHK(hipFree(*T.stage));
                 *T.stage = nullptr; *T.stage_bytes = 0;
-                if (hipMalloc((void**)T.stage, need) != hipSuccess)
+                hipError_t me = hipMalloc((void**)T.stage, need);
+                if (me != hipSuccess && need > exact) { (void)hipGetLastError(); need = exact; me = hipMalloc((void**)T.stage, need); }
+                if (me != hipSuccess)
                 {
                     // another allocator took the memory since it was measured: a smaller batch renders the same bits
                     (void)hipGetLastError();
@@ -1175,43 +1202,62 @@ void render_key(const Param* p, std::vector<unsigned char>& key)
 // render_kernel with frame look-ahead.  The reference host calls render_kernel once per frame and synchronises
 // (host.cpp:631-632); a one-frame launch is bound by its longest path (about 14 ms for 0.48 M samples, 12x off the
 // batched rate).  A sample is a pure function of (x, y, frame, scene), so when the host asks for frame f right after
-// f-1 with nothing changed, frames f..f+n-1 are rendered in ONE launch into a staging slot (n doubles per consecutive
-// miss up to la_max) and only frame f is added to the caller's accumulator; the next calls find their frame staged and
-// just add it.  Once n has reached la_max two slots are kept in flight on two streams, so the tail of one batch (its
+// f-1 with nothing changed, frames f..f+n-1 are rendered in ONE launch into a staging slot (n = 8, 16, ... la_max)
+// and only frame f is added to the caller's accumulator; the next calls find their frame staged and
+// just add it.  Two slots are kept in flight on two streams -- the successor of a batch (twice its size, up to la_max) is queued
+// when the batch's first frame is asked for --, so the tail of one batch (its
 // deepest paths) overlaps the body of the next.  Any state change drops the staged frames.  Bit-identical to one
 // launch per frame.
-int la_quiesce()
+// Batches in flight whose frames nobody will ask for any more (a setter, a camera move, new device contents, a frame jump) are told
+// to stop -- unless a frame of the batch has already been handed out (its add-kernel sits on the caller's stream behind the
+// batch's completion event and needs that frame whole: such a batch runs to its end).  The slot's cancel word gets the batch's
+// number: its render_k takes no further chunk (it asks at every chunk, in every launch of a multi-launch batch), approach kernels
+// that have not started yet return at once, and the waves of render_k<..., CANCEL> give up their paths at their next look at the
+// word (every eighth event visit; nothing reads what a cancelled batch has staged): a camera move waits 0.3 ms instead of the rest
+// of the batch or its deepest paths.  Numbers only grow, so nothing has to be re-armed and a cancel can neither be lost nor reach a
+// later batch.  Written from a stream of the highest priority (State::ctrl_stream: a hardware queue of its own);
+// results are discarded, so nothing depends on where the cut falls.  Does not wait.  Whether the slot's frames are still VALID
+// for serving does not matter here: a miss invalidates the slots first and finds the batches running all the same.
+bool la_cancel_running()
 {
-    // Every caller is about to drop the staged frames (a setter, a camera move, new device contents): what a batch still in
-    // flight would render is of no use -- unless a frame of it has already been handed out (its add-kernel sits on the caller's
-    // stream behind the batch's completion event and needs that frame whole: such a batch runs to its end).  The slot's cancel
-    // word gets the batch's number: its render_k takes no further chunk (it asks at every chunk, in every launch of a multi-launch
-    // batch), approach kernels that have not started yet return at once, and the kernels drain the paths already running: a
-    // camera move waits a millisecond or two instead of the rest of a 64-frame batch.  Numbers only grow, so nothing has to be
-    // re-armed and a cancel can neither be lost to a memset queued behind it nor reach a later batch.  Written from a
-    // stream of its own (the batch's stream is busy with the batch); results are discarded, so nothing depends on where the cut falls.
     bool any = false;
     bool cancel[2] = {false, false};
     for (int si = 0; si < 2 && G.la_cancel; si++)
-        if (G.la[si].stream && G.la[si].done && G.la[si].valid && !G.la[si].touched && hipEventQuery(G.la[si].done) == hipErrorNotReady) cancel[si] = any = true;
+        if (G.la[si].stream && G.la[si].done && !G.la[si].touched && G.la[si].cancel_seq != G.batch_seq[si + 1] && hipEventQuery(G.la[si].done) == hipErrorNotReady)
+            cancel[si] = any = true;
     (void)hipGetLastError();
-    if (any)
+    if (!any) return false;
+    if (!G.ctrl_stream)
     {
-        if (!G.ctrl_stream && hipStreamCreateWithFlags(&G.ctrl_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); G.ctrl_stream = nullptr; }
-        if (G.ctrl_stream)
-        {
-            for (int si = 0; si < 2; si++)
-                if (cancel[si])
-                    (void)hipMemsetD32Async((hipDeviceptr_t)(G.d_cancel + (si + 1)), (int)G.batch_seq[si + 1], 1, G.ctrl_stream);
-            (void)hipGetLastError();
-        }
+        int lo = 0, hi = 0;   // (numerically lower = higher priority)
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        if (hipStreamCreateWithPriority(&G.ctrl_stream, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); G.ctrl_stream = nullptr; }
     }
+    if (!G.ctrl_stream) return false;
+    for (int si = 0; si < 2; si++)
+        if (cancel[si])
+        {
+            G.la_cancelled++;
+            G.la[si].cancel_seq = G.batch_seq[si + 1];   // (told once)
+            (void)hipMemsetD32Async((hipDeviceptr_t)(G.d_cancel + (si + 1)), (int)G.batch_seq[si + 1], 1, G.ctrl_stream);
+        }
+    (void)hipGetLastError();
+    return true;
+}
+int la_quiesce()
+{
+    // every caller is about to change what batches in flight read (tables, lists, the volume): stop them and wait
+    const bool any = la_cancel_running();
+    static const bool dbg = getenv("VP_DEBUG_QUIESCE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     for (auto& s : G.la)
     {
         if (s.stream) HIPCHK(hipStreamSynchronize(s.stream));
         s.valid = false;
     }
     if (any && G.ctrl_stream) HIPCHK(hipStreamSynchronize(G.ctrl_stream));
+    if (dbg && any)
+        fprintf(stderr, "[vp] quiesce: batches stopped and drained after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return VP_OK;
 }
 int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, const std::vector<unsigned char>& key)
@@ -1233,6 +1279,7 @@ int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, c
     HIPCHK(hipStreamWaitEvent(s.stream, ev, 0));
     put_event(ev);
     const Target t = {s.stream, &s.buf, &s.bytes, G.d_queue + 2 * kQueueWords * (si + 1), si + 1};
+    G.la_launched++;
     G.batch_seq[si + 1]++;   // (numbers only grow: a cancel of an earlier batch of this slot can never reach this one)
     int rc = do_render(d_out, first, n, p, true, &t);
     if (rc) return rc;
@@ -1264,9 +1311,15 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
         // (the add-kernels that read the other slot) and can fill the tail of the batch now finishing.
         auto& o = G.la[si ^ 1];
         const int next = s.first + s.count;
-        if (frame == s.first && s.count >= G.la_max && !(o.valid && o.key == key && o.first == next))
+        // (during the ramp as well: the batch after a batch of n is one of 2n, queued when the first frame of this one is asked for)
+        if (frame == s.first && s.count >= G.la_overlap_from && !(o.valid && o.key == key && o.first == next))
         {
-            int n = la_limit(next, G.la_max, per_frame, o.bytes);
+            // twice this one, up to la_max -- but beyond la_floor frames never more than half of what the run has accumulated by then: a
+            // batch is delivered whole (its first frame waits for its last), so a big one early in a run is a long wait for few frames,
+            // and most of it is thrown away when the camera moves on after a few hundred frames
+            int want = std::min(s.count * 2, G.la_max);
+            while (want > G.la_floor && want > (next - G.la_run_first) / G.la_div) want >>= 1;
+            int n = la_limit(next, want, per_frame, o.bytes);
             if (n > 1 && la_render_slot(si ^ 1, d_out, next, n, p, key)) G.la[si ^ 1].valid = false;  // best effort
         }
         // hit: add the staged frame once its batch is rendered
@@ -1281,15 +1334,33 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
         launch_reduce(L, G.stream);
         HIPCHK(hipGetLastError());
         G.la_last = frame;
+        G.la_habit = true;   // this caller asks for consecutive frames
         return VP_OK;
     }
     // miss: how far ahead?  only when this call continues the previous one
     const bool same = key == G.la_key;
-    int n = (same && frame == G.la_last + 1) ? std::min(std::max(G.la_prev_n, 1) * 2, G.la_max) : 1;
+    // (the first frame of a run alone: it is what the caller waits for after a camera move, ~10 ms of its deepest paths; the call
+    // after it starts the ramp at la_ramp_from frames -- a batch of up to ~32 frames lasts as long as one frame, its deepest path --
+    // and every batch has its successor, twice its size, queued behind it)
+    int n = (same && frame == G.la_last + 1) ? std::min(std::max(G.la_prev_n * 2, G.la_ramp_from), std::min(G.la_max, G.la_floor)) : 1;
+    if (n == 1) G.la_run_first = frame;
     if (n > 1) n = std::max(la_limit(frame, n, per_frame, G.la[0].bytes), 1);
     G.la_key = key; G.la_last = frame; G.la_prev_n = n;
+    (void)la_cancel_running();   // (what runs ahead for frames that will not be asked for: out of this frame's way)
     G.la[0].valid = G.la[1].valid = false;
-    if (n <= 1 || !per_frame || !d_out) return do_render(d_out, frame, 1, p);
+    if (n <= 1 || !per_frame || !d_out)
+    {
+        // The first frame of a run (after a camera move, a setter, a frame jump) is rendered alone: it is what the caller waits for.  A
+        // caller that has been asking for consecutive frames will ask for the next ones: the first batch of the ramp is queued on a slot
+        // BEFORE this frame's launch (the slot's stream waits for what is on the caller's stream now), so the two run side by side --
+        // both are bound by their deepest paths, not by the chip.
+        if (G.la_habit && G.la_speculate && per_frame && d_out && n == 1)
+        {
+            const int m = la_limit(frame + 1, std::min(G.la_ramp_from, std::min(G.la_max, G.la_floor)), per_frame, G.la[0].bytes);
+            if (m > 1 && la_render_slot(0, d_out, frame + 1, m, p, key)) G.la[0].valid = false;   // best effort
+        }
+        return do_render(d_out, frame, 1, p);
+    }
     // The look-ahead is an optimisation the caller never asked for: if the batch cannot be rendered (no memory for its
     // staging slot, a stream that cannot be created) this frame is rendered alone, exactly as without look-ahead, and
     // the batch size starts over.
@@ -1478,9 +1549,9 @@ int vp_ctx_destroy(vp_ctx* ctx)
             if (D.d_appr_aux[i]) (void)hipFree(D.d_appr_aux[i]);
             for (int q = 0; q < 2; q++) if (D.aux_ev[i][q]) (void)hipEventDestroy(D.aux_ev[i][q]);
         }
-        if (D.ctrl_stream) (void)hipStreamDestroy(D.ctrl_stream);
         if (D.d_queue) (void)hipFree(D.d_queue);
         if (D.d_counters) (void)hipFree(D.d_counters);
+        if (D.ctrl_stream) (void)hipStreamDestroy(D.ctrl_stream);
         if (D.d_cancel) (void)hipFree(D.d_cancel);
         if (D.own_stream) (void)hipStreamDestroy(D.own_stream);
     }
@@ -1644,6 +1715,12 @@ int vp_render_time_ms(double* total_ms, int* launches, int reset)
 }
 int vp_last_approach_mode(void) { return G.last_approach; }
 int vp_last_light_const(void) { return G.last_light_const; }
+int vp_lookahead_stats(unsigned* launched, unsigned* cancelled_in_flight)
+{
+    if (launched) *launched = G.la_launched;
+    if (cancelled_in_flight) *cancelled_in_flight = G.la_cancelled;
+    return VP_OK;
+}
 int vp_render_class_time_ms(double ms[3], unsigned pixels[3], int reset)
 {
     int rc = ensure_device();

@@ -203,7 +203,7 @@ __global__ void light_identity_k(ParamDev P, int local, const unsigned* mask, un
                                // spill four or five at six waves and run as the LDS-table kernel's helper workgroups, where a fifth wave is
                                // all a SIMD has room for: they keep five
 #endif
-template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool MIS, int TRK, bool LIGHT = false>
+template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool MIS, int TRK, bool LIGHT = false, bool CANCEL = false>
 // Occupancy (round 4: the cold per-path state in LDS, ColdVal above; profiles/r04_kernel_resources.txt).  The achromatic
 // global-majorant kernel needs 72 registers: SEVEN waves per SIMD (C2 2541 -> 2781 Msamples/s); the chromatic one and the plain
 // achromatic local-majorant kernels 80: six (c3ref 2398 -> 2513); the LDS-table kernel keeps its state in registers (its LDS is the
@@ -317,6 +317,7 @@ void render_k(SceneDev S, LaunchDev L)
     unsigned q_cur   = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & (VP_NQUEUES - 1);
     unsigned q_tried = 0;
     unsigned end_skipped = 0;   // event visits since the path-end chain last ran (wave-uniform)
+    unsigned visits = 0;        // CANCEL: event visits of this wave (wave-uniform)
 
     for (;;)
     {
@@ -860,6 +861,18 @@ void render_k(SceneDev S, LaunchDev L)
             if (__ballot((st == ST_DONE && !exhausted) || st == EV_BG || st == EV_WRITE) == 0ull) break;
         }
 ends_done:
+        // CANCEL: the instance look-ahead batches run (render_kernel's staged frames, LaunchDev::cancel).  A batch the host has dropped --
+        // a camera move, a setter -- is of no use to anybody: every wave asks at every eighth event visit (a visit comes every ~15 us)
+        // and gives up its paths at once instead of tracing them to their ends, which is what the move would otherwise wait for (the
+        // deepest paths in flight: ~10 ms).  Nothing reads what such a batch has staged.  An instance of its own because the test,
+        // small as it is, reshuffles the registers of the batched global-majorant kernel to the tune of -4...-5.5 %
+        // (profiles/experiments/r04_lookahead_cancel.txt).
+        if (CANCEL && L.cancel && (visits++ & 7u) == 0u)
+        {
+            unsigned w = 0;
+            if (lane == 0) w = atomicOr(L.cancel, 0u);
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)w) >= L.batch_id) { st = ST_DONE; exhausted = true; queue_empty = true; }
+        }
         if (__ballot(st != ST_DONE || !exhausted) == 0ull) break;  // queue drained and every lane idle
         }
         if (COUNT) { unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) t_slow += t - t_mark; t_mark = t; }
@@ -2106,17 +2119,22 @@ static void launch_render5(const SceneDev& S, const LaunchDev& L, bool quant, bo
     if constexpr (!MIS)
     {
         if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB, ACH, false, 0>), dim3(blocks), blk, 0, st, S, L);
+        else if (L.cancel) hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB, ACH, false, 0, false, true>), dim3(blocks), blk, 0, st, S, L);
         else hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB, ACH, false, 0>), dim3(blocks), blk, 0, st, S, L);
     }
 #else
+    // (look-ahead batches of the shipped configuration -- passive environment -- run the instance that can be stopped at once: CANCEL)
+    constexpr bool CAN = !MIS;
     if (quant)
     {
         if (count) hipLaunchKernelGGL((render_k<EST, RNG, true, true, LDSB, ACH, MIS, 0>), dim3(blocks), blk, 0, st, S, L);
+        else if (CAN && L.cancel) hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB, ACH, MIS, 0, false, CAN>), dim3(blocks), blk, 0, st, S, L);
         else hipLaunchKernelGGL((render_k<EST, RNG, true, false, LDSB, ACH, MIS, 0>), dim3(blocks), blk, 0, st, S, L);
     }
     else
     {
         if (count) hipLaunchKernelGGL((render_k<EST, RNG, false, true, false, ACH, MIS, 0>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
+        else if (CAN && L.cancel) hipLaunchKernelGGL((render_k<EST, RNG, false, false, false, ACH, MIS, 0, false, CAN>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
         else hipLaunchKernelGGL((render_k<EST, RNG, false, false, false, ACH, MIS, 0>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
     }
 #endif

@@ -24,7 +24,7 @@ PART1_SYMBOLS = ["init_cuda", "set_texture_filter_mode", "free_cuda_buffers", "p
                  "render_kernel", "scale", "gamma_correct"]
 PART2_SYMBOLS = ["vp_last_error", "vp_version", "vp_device_count", "vp_set_device", "vp_set_stream", "vp_get_stream", "vp_synchronize",
                  "vp_set_estimator", "vp_set_rng", "vp_set_envmap_sampling", "vp_get_env_tables", "vp_set_lookahead", "vp_set_tracking", "vp_set_bound_brick", "vp_set_shard", "vp_render_frames",
-                 "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity", "vp_get_pixel_table", "vp_get_null_collision_table", "vp_get_sun_clip_table", "vp_get_exit_table", "vp_set_exit_flights", "vp_render_class_time_ms", "vp_last_approach_mode", "vp_last_light_const", "vp_prepare", "vp_reserve_frames", "vp_get_pixel_lists",
+                 "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity", "vp_get_pixel_table", "vp_get_null_collision_table", "vp_get_sun_clip_table", "vp_get_exit_table", "vp_set_exit_flights", "vp_render_class_time_ms", "vp_last_approach_mode", "vp_last_light_const", "vp_lookahead_stats", "vp_prepare", "vp_reserve_frames", "vp_get_pixel_lists",
                  "vp_julia_voxelize", "vp_cloud_voxelize", "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_test_hg", "vp_test_intersect_box",
                  "vp_test_eval_envmap", "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_current", "vp_ctx_get_current", "vp_ctx_device",
                  "vp_accumulate", "vp_tile_owner", "vp_malloc", "vp_free", "vp_memset",
@@ -261,8 +261,11 @@ def set_tracking(mode):
     _chk(lib().vp_set_tracking(mode))
 
 
-def set_lookahead(max_frames):
-    """frames render_kernel may render ahead per launch (0/1: one launch per call)"""
+LOOKAHEAD_DEFAULT = 256
+
+
+def set_lookahead(max_frames=LOOKAHEAD_DEFAULT):
+    """frames render_kernel may render ahead per launch (0/1: one launch per call; default 256)"""
     _chk(lib().vp_set_lookahead(max_frames))
 
 
@@ -328,6 +331,13 @@ def last_approach_mode():
 def reserve_frames(P, nframes):
     """size the sample staging for a coming render_frames job of nframes now (vp_reserve_frames)"""
     _chk(lib().vp_reserve_frames(C.byref(P), int(nframes)))
+
+
+def lookahead_stats():
+    """(look-ahead batches launched, batches told to stop while still running) of the current context (vp_lookahead_stats)"""
+    a, b = C.c_uint(0), C.c_uint(0)
+    _chk(lib().vp_lookahead_stats(C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
 
 
 def last_light_const():

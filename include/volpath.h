@@ -159,7 +159,9 @@ enum { VP_TRACK_SPECTRAL = 0, VP_TRACK_SCALAR = 1, VP_TRACK_MULTI_CHANNEL = 2 };
 int vp_set_tracking(int mode);                         /* default VP_TRACK_SPECTRAL */
 /* render_kernel renders up to max_frames consecutive frames per launch when the host asks for frame f right after f-1 with
  * unchanged state, stages them, and serves the following calls from the staged frames (bit-identical to one launch per
- * frame).  Default 64; 0 or 1 = one launch per call.  Env: VP_LOOKAHEAD. */
+ * frame).  The first frame of a run is rendered alone, then batches of 8, 16, ... frames, each with its
+ * successor queued behind it; beyond 64 a batch is at most half of what the run has accumulated.  A setter or a camera move
+ * stops the batches in flight within a fraction of a millisecond.  Default 256; 0 or 1 = one launch per call.  Env: VP_LOOKAHEAD. */
 int vp_set_lookahead(int max_frames);
 enum { VP_ENV_PASSIVE = 0, VP_ENV_MIS = 1 };
 int vp_set_envmap_sampling(int mode);                  /* default VP_ENV_PASSIVE */
@@ -212,6 +214,9 @@ int vp_last_approach_mode(void);
 /* 1 if the last render call of this context wrote its light class (pixels whose camera ray meets empty cells only) as per-pixel
  * constants (miss_fill_k: a null collision in empty space leaves a throughput of 1 as it is in this medium), 0 if it integrated it. */
 int vp_last_light_const(void);
+/* test hook: look-ahead batches this context has launched so far (render_kernel's staged frames), and how many of them were told to
+ * stop while they were still running (a setter, a camera move); either pointer may be NULL */
+int vp_lookahead_stats(unsigned* launched, unsigned* cancelled_in_flight);
 /* Builds everything a render of this Param would build first -- the per-pixel tables of the current camera, the pixel lists
  * of the shard, the sun table -- and waits for it.  A host that moves the camera may call it to take that work out of its
  * first frame; bench.py times it (per_camera_setup_ms).  Not needed for correctness: render_kernel does the same on demand. */

@@ -252,7 +252,7 @@ def test_event_ring_stays_bounded_and_oom_is_reported(vp, oracle):
         assert n == 300 and ms > 0                       # all 300 launches counted, although only 64 pairs are kept pending
         buf.free()
     finally:
-        vp.set_lookahead(64)
+        vp.set_lookahead(vp.LOOKAHEAD_DEFAULT)
     L = vp.lib()
     assert L.vp_malloc(1 << 50) is None                  # 1 PiB
     assert b"VP_E_NOMEM" in L.vp_last_error() or b"memory" in L.vp_last_error().lower()
@@ -447,6 +447,46 @@ def test_class_times_and_prepare(vp):
     assert launches >= 1 and total >= max(ms.values()) * 0.9
     ms2, _ = vp.render_class_time_ms(reset=True)
     assert all(v == 0 for v in ms2.values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["c1", "c2"])
+def test_camera_move_stops_lookahead_batches_in_flight(vp, workload):
+    """The reference's interactive loop: render_kernel frame by frame, then the camera moves (host.cpp:617-632).  The batches
+    render_kernel has staged ahead are told to stop while they run (LaunchDev::cancel, render_k<..., CANCEL>); frames already handed
+    out must be whole, the frames after the move must be those of the new camera: both equal the explicit batch call without
+    look-ahead, bit for bit.  At a size where batches ARE still running when the move comes (vp_lookahead_stats says so)."""
+    from volpath import scene as vscene, host
+    P, info = vscene.setup(workload, rng_mode=vp.RNG_PHILOX7, last_frame=80)
+    W, H = P.width, P.height
+    cam1 = info["camera"]
+    cam2 = tuple(float(v) for v in host.camera_matrix((3.9 * np.cos(0.7), -0.78, 3.9 * np.sin(0.7)), (-np.cos(0.7), 0.2, -np.sin(0.7)), (0.0, 1.0, 0.0)))
+    vp.set_lookahead(vp.LOOKAHEAD_DEFAULT)
+    a, b, ref = vp.DeviceBuffer(W, H), vp.DeviceBuffer(W, H), vp.DeviceBuffer(W, H)
+    try:
+        vp.synchronize()
+        l0, c0 = vp.lookahead_stats()
+        n1, n2 = 40, 12
+        for f in range(n1):
+            vp.render_kernel(a.ptr, f, P)          # the reference's loop: one call per frame, a synchronisation after each
+            vp.synchronize()                       # (host.cpp:631-632); the batch behind the one being served runs meanwhile
+        vp.set_camera(cam2)                        # the move: what is staged ahead is dropped, what runs is stopped
+        for f in range(n2):
+            vp.render_kernel(b.ptr, f, P)
+        l1, c1 = vp.lookahead_stats()              # (the batches are stopped where the new camera is first used)
+        got_a, got_b = a.download(), b.download()
+        assert l1 - l0 >= 3, "the look-ahead did not ramp"
+        assert c1 - c0 >= 1, "no batch was in flight at the move: the test does not exercise the cancellation"
+        vp.set_lookahead(0)
+        vp.render_frames(ref.ptr, 0, n2, P)
+        assert np.array_equal(got_b, ref.download()), "frames after the move"
+        vp.set_camera(cam1)
+        ref.reset()
+        vp.render_frames(ref.ptr, 0, n1, P)
+        assert np.array_equal(got_a, ref.download()), "frames handed out before the move"
+    finally:
+        vp.set_lookahead(vp.LOOKAHEAD_DEFAULT)
+        a.free(); b.free(); ref.free()
 
 
 # ------------------------------------------------------------------ c4f: the same shape with a volume that fills the frame

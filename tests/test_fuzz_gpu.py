@@ -267,7 +267,7 @@ def _run_call_sequence(vp, oracle, seed, extra):
             elif u < 0.93:
                 st["env_seed"] = int(rng.integers(0, 100)); vp.init_envmap(scenes.synthetic_env(seed=st["env_seed"])); osc = make_oracle(); log.append("env")
             elif u < 0.96:
-                vp.set_lookahead(int(rng.choice([0, 2, 8, 64]))); log.append("lookahead")
+                vp.set_lookahead(int(rng.choice([0, 2, 8, 64, 256]))); log.append("lookahead")
             elif extra and u < 0.975:
                 vp.prepare(P_v); log.append("prepare")
             elif extra and u < 0.985:
@@ -280,7 +280,7 @@ def _run_call_sequence(vp, oracle, seed, extra):
         for b, r in zip(bufs, refs):
             assert np.array_equal(b.download(), r, equal_nan=True), (seed, "end", log[-12:])
     finally:
-        vp.set_lookahead(64)
+        vp.set_lookahead(vp.LOOKAHEAD_DEFAULT)
         vp.set_camera()
         for b in bufs:
             b.free()
