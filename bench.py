@@ -383,6 +383,46 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
     return out
 
 
+def reference_call_pattern(workload, args, ctx, frames=1200, moves=12, frames_per_move=32):
+    """The reference host's OWN call pattern under the driver's clock: one render_kernel per frame with a synchronisation after each
+    (src/volumeRender.cpp:631-632), `frames` of them on the resting camera; then the interactive case -- the camera orbits, every move
+    resets the accumulation (:617-625) -- `moves` x `frames_per_move`.  Same entry point, same bits as the batched job (render_kernel
+    stages frames ahead: DESIGN.md section 7); reported beside the headline, never as `value`."""
+    import numpy as np
+    import torch
+    import volpath as vp
+    from volpath import scene as vscene, host as vhost
+    rng_mode = {"philox": vp.RNG_PHILOX, "philox7": vp.RNG_PHILOX7, "samplerh": vp.RNG_SAMPLERH}[args.rng]
+    P, info = vscene.setup(workload, rng_mode=rng_mode, last_frame=frames + 8, sunsky=ctx.get("sunsky"))
+    W, H = P.width, P.height
+    with torch.cuda.stream(ctx["stream"]):
+        acc = torch.zeros(H, W, 4, device=ctx["dev"], dtype=torch.float32)
+        for f in range(4):                      # clocks, tables, staging slots
+            vp.render_kernel(acc.data_ptr(), f, P); vp.synchronize()
+        acc.zero_(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in range(frames):
+            vp.render_kernel(acc.data_ptr(), f, P); vp.synchronize()
+        wall = time.perf_counter() - t0
+        first, t1 = [], time.perf_counter()
+        for m in range(moves):
+            a = 2.0 * np.pi * m / moves
+            cam = vhost.camera_matrix((3.9 * np.cos(a), -0.78, 3.9 * np.sin(a)), (-np.cos(a), 0.2, -np.sin(a)), (0.0, 1.0, 0.0))
+            vp.set_camera(tuple(float(v) for v in cam))
+            acc.zero_()
+            for f in range(frames_per_move):
+                t = time.perf_counter(); vp.render_kernel(acc.data_ptr(), f, P); vp.synchronize()
+                if f == 0:
+                    first.append((time.perf_counter() - t) * 1e3)
+        orbit = time.perf_counter() - t1
+        vp.set_camera(info["camera"])
+        vp.synchronize()
+    return {"workload": workload, "calls": "one render_kernel per frame, a synchronisation after each (src/volumeRender.cpp:631-632)",
+            "frames": frames, "msamples_per_s": W * H * frames / wall / 1e6, "wall_ms": wall * 1e3,
+            "orbit": {"moves": moves, "frames_per_move": frames_per_move, "msamples_per_s": W * H * moves * frames_per_move / orbit / 1e6,
+                      "first_frame_after_a_move_ms_median": float(np.median(first)), "note": "set_camera + first frame: the per-camera tables, stopping the batches in flight, one one-frame launch"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -452,6 +492,9 @@ def main():
         strong = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, "strong", full=False, split="tiles")
         if args.split in ("auto", "frames") and args.spp % world == 0:
             strong_alt = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, "strong", full=False, split="frames")
+    call_pattern = None
+    if world == 1 and not args.no_secondary:
+        call_pattern = reference_call_pattern(args.workload, args, ctx)
     secondary = {}
     if world == 1 and args.workload == "c2" and not args.no_secondary:
         # The workloads that do physics in every pixel, or on the reference's own streams, under the same clock as the headline
@@ -494,6 +537,8 @@ def main():
             out["strong"]["split"] = best
             out["strong"]["by_split"] = {k: {"value": v["value"], "ms_per_step": v["ms_per_step"], "parallelism": v["config"]["parallelism"],
                                              "balance_max_over_mean": v.get("ranks", {}).get("balance_max_over_mean")} for k, v in both.items()}
+        if call_pattern:
+            out["reference_call_pattern"] = call_pattern
         if secondary:
             out["secondary"] = secondary
         if args.dump_image:

@@ -307,6 +307,17 @@ int ensure_device()
 }
 
 int la_quiesce();
+// The library's internal streams -- look-ahead slots, the light kernel's / helper workgroups' side streams -- have the LOWEST priority:
+// streams of one priority share a pool of four hardware queues, and among a caller's ordinary streams an internal stream came to
+// share a queue with the caller's (whose kernels wait for events of the other internal streams): what was meant to overlap ran in
+// turn (host loop 2030 -> 1635 Msamples/s with one extra stream in the process).  What runs ahead or beside also SHOULD yield to
+// what the caller asked for.
+hipError_t create_internal_stream(hipStream_t* st)
+{
+    int lo = 0, hi = 0;   // (numerically greater = lower priority)
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, lo);
+}
 
 int free_volume()
 {
@@ -1085,7 +1096,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                 if (both && G.light_overlap)
                 {
                     const int ti = T.index;
-                    if (!G.aux_stream[ti] && hipStreamCreateWithFlags(&G.aux_stream[ti], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); G.aux_stream[ti] = nullptr; }
+                    if (!G.aux_stream[ti] && create_internal_stream(&G.aux_stream[ti]) != hipSuccess) { (void)hipGetLastError(); G.aux_stream[ti] = nullptr; }
                     for (int q = 0; q < 2; q++)
                         if (!G.aux_ev[ti][q] && hipEventCreateWithFlags(&G.aux_ev[ti][q], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G.aux_ev[ti][q] = nullptr; }
                     // the auxiliary stream starts at the fork point recorded above (queue heads zeroed, the previous launch's reduce,
@@ -1144,7 +1155,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                 if (lds_helper && ldsb && le == hipSuccess && fork_recorded && blocks >= cap)
                 {
                     const int ti = T.index;
-                    if (!G.aux_stream[ti] && hipStreamCreateWithFlags(&G.aux_stream[ti], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); G.aux_stream[ti] = nullptr; }
+                    if (!G.aux_stream[ti] && create_internal_stream(&G.aux_stream[ti]) != hipSuccess) { (void)hipGetLastError(); G.aux_stream[ti] = nullptr; }
                     if (!G.aux_ev[ti][1] && hipEventCreateWithFlags(&G.aux_ev[ti][1], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G.aux_ev[ti][1] = nullptr; }
                     if (G.aux_stream[ti] && G.aux_ev[ti][1] && hipStreamWaitEvent(G.aux_stream[ti], G.aux_ev[ti][0], 0) == hipSuccess)
                     {
@@ -1263,7 +1274,10 @@ int la_quiesce()
 int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, const std::vector<unsigned char>& key)
 {
     auto& s = G.la[si];
-    if (!s.stream) HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    if (!s.stream)
+    {
+        HIPCHK(create_internal_stream(&s.stream));   // (lowest priority: see there)
+    }
     if (!s.done) HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     s.valid = false;
     // `touched` guards the batch that is being replaced as well: it may still be running on this stream (a miss invalidates a slot
