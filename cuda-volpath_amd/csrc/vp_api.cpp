@@ -65,6 +65,7 @@ struct State
         hipStream_t stream = nullptr;
         hipEvent_t  done = nullptr;   // recorded after the batch's render
         bool        valid = false;
+        unsigned    launched_seq = 0; // the number of the batch whose completion `done` stands for (the slot's batch_seq while no launch is under way)
         unsigned    cancel_seq = 0;   // the number of the batch of this slot that was last told to stop (la_cancel_running)
         bool        touched = false;  // a frame of this batch was handed to the caller while the batch was still running: its add-kernel
                                       // waits for the WHOLE batch, which must then run to its end (la_quiesce does not cancel it)
@@ -1234,7 +1235,10 @@ bool la_cancel_running()
     bool any = false;
     bool cancel[2] = {false, false};
     for (int si = 0; si < 2 && G.la_cancel; si++)
-        if (G.la[si].stream && G.la[si].done && !G.la[si].touched && G.la[si].cancel_seq != G.batch_seq[si + 1] && hipEventQuery(G.la[si].done) == hipErrorNotReady)
+        // (the batch `done` stands for -- launched_seq -- not the slot's newest number: this runs INSIDE the launch of a slot's next
+        // batch too, when a table has to be rebuilt first, and the number of a batch about to start must not get into its cancel word)
+        if (G.la[si].stream && G.la[si].done && !G.la[si].touched && G.la[si].launched_seq && G.la[si].cancel_seq != G.la[si].launched_seq &&
+            hipEventQuery(G.la[si].done) == hipErrorNotReady)
             cancel[si] = any = true;
     (void)hipGetLastError();
     if (!any) return false;
@@ -1249,8 +1253,8 @@ bool la_cancel_running()
         if (cancel[si])
         {
             G.la_cancelled++;
-            G.la[si].cancel_seq = G.batch_seq[si + 1];   // (told once)
-            (void)hipMemsetD32Async((hipDeviceptr_t)(G.d_cancel + (si + 1)), (int)G.batch_seq[si + 1], 1, G.ctrl_stream);
+            G.la[si].cancel_seq = G.la[si].launched_seq;   // (told once)
+            (void)hipMemsetD32Async((hipDeviceptr_t)(G.d_cancel + (si + 1)), (int)G.la[si].launched_seq, 1, G.ctrl_stream);
         }
     (void)hipGetLastError();
     return true;
@@ -1298,6 +1302,7 @@ int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, c
     int rc = do_render(d_out, first, n, p, true, &t);
     if (rc) return rc;
     HIPCHK(hipEventRecord(s.done, s.stream));
+    s.launched_seq = G.batch_seq[si + 1];
     s.valid = true; s.first = first; s.count = n; s.key = key;
     return VP_OK;
 }

@@ -284,3 +284,66 @@ def _run_call_sequence(vp, oracle, seed, extra):
         vp.set_camera()
         for b in bufs:
             b.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,seed", [("c2" if k % 4 == 2 else "c1", k) for k in range(int(__import__("os").environ.get("VP_FUZZ_INFLIGHT", "8")))])
+def test_call_sequences_with_batches_in_flight(vp, workload, seed):
+    """The call-sequence fuzz above runs on scenes a launch finishes in microseconds: nothing is ever in flight when a setter comes.
+    Here the same kind of sequence at sizes where render_kernel's staged batches ARE running when the camera moves, a Param changes,
+    the look-ahead depth changes or the host jumps to another frame or accumulator -- with and without a synchronisation after each
+    call.  Every accumulator must equal its replay through the explicit batch call with the look-ahead off (which the parity tests tie
+    to the oracle), bit for bit; vp_lookahead_stats must show that batches were stopped while running."""
+    from volpath import scene as vscene, host
+    rng = np.random.default_rng(4200 + seed)
+    P0, info = vscene.setup(workload, rng_mode=vp.RNG_SAMPLERH if seed % 4 == 1 else vp.RNG_PHILOX7, last_frame=400)
+    W, H = P0.width, P0.height
+    bufs = [vp.DeviceBuffer(W, H), vp.DeviceBuffer(W, H)]
+    ref = vp.DeviceBuffer(W, H)
+    cams = [info["camera"]]
+    for a in rng.uniform(0, 2 * np.pi, 5):
+        cams.append(tuple(float(v) for v in host.camera_matrix((3.9 * np.cos(a), -0.78, 3.9 * np.sin(a)), (-np.cos(a), 0.2, -np.sin(a)), (0.0, 1.0, 0.0))))
+    segs, cur, cam, density, frame = [], 0, 0, 100.0, 0
+    vp.set_lookahead(vp.LOOKAHEAD_DEFAULT)
+    vp.synchronize()
+    l0, c0 = vp.lookahead_stats()
+    try:
+        for seg in range(28):
+            u = rng.random()
+            if u < 0.45:
+                cam = int(rng.integers(0, len(cams))); vp.set_camera(cams[cam]); frame = 0
+            elif u < 0.60:
+                density = float(np.float32(rng.uniform(60, 300)))
+            elif u < 0.70:
+                vp.set_lookahead(int(rng.choice([0, 8, 64, 256])))
+            elif u < 0.80:
+                cur = 1 - cur
+            elif u < 0.90:
+                frame = int(rng.integers(0, 300))          # a frame jump inside a run
+            P = vp.make_param(W, H, density=density)
+            n = int(rng.choice([1, 2, 5, 12, 30, 45, 70]))
+            sync = rng.random() < 0.7                       # the reference's loop synchronises after every call
+            for f in range(frame, frame + n):
+                vp.render_kernel(bufs[cur].ptr, f, P)
+                if sync:
+                    vp.synchronize()
+            segs.append((cur, cam, density, frame, n))
+            frame += n
+        got = [b.download() for b in bufs]
+        l1, c1 = vp.lookahead_stats()
+        if seed < 8:   # (the default seeds are known to run many batches and to stop several in flight; a random sequence may not)
+            assert l1 - l0 >= 10 and c1 - c0 >= 3, (l1 - l0, c1 - c0)
+        vp.set_lookahead(0)
+        for i in range(2):
+            ref.reset()
+            for (b, cm, dn, f0, n) in segs:
+                if b == i:
+                    vp.set_camera(cams[cm])
+                    vp.render_frames(ref.ptr, f0, n, vp.make_param(W, H, density=dn))
+            assert np.array_equal(got[i], ref.download(), equal_nan=True), (workload, seed, i, segs)
+    finally:
+        vp.set_lookahead(vp.LOOKAHEAD_DEFAULT)
+        vp.set_camera()
+        for b in bufs:
+            b.free()
+        ref.free()
