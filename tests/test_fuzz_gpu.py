@@ -296,7 +296,19 @@ def test_call_sequences_with_batches_in_flight(vp, workload, seed):
     to the oracle), bit for bit; vp_lookahead_stats must show that batches were stopped while running."""
     from volpath import scene as vscene, host
     rng = np.random.default_rng(4200 + seed)
-    P0, info = vscene.setup(workload, rng_mode=vp.RNG_SAMPLERH if seed % 4 == 1 else vp.RNG_PHILOX7, last_frame=400)
+    rng_mode = vp.RNG_SAMPLERH if seed % 4 == 1 else vp.RNG_PHILOX7
+    key = (0x9E3779B9, 0x85EBCA6B)
+    P0, info = vscene.setup(workload, rng_mode=rng_mode, key=key, last_frame=400)
+    env, sun_dir, sun_power = info["sunsky"]
+    suns = [tuple(sun_dir), tuple(float(np.float32(v)) for v in np.array([0.3, 0.8, -0.52]) / np.linalg.norm([0.3, 0.8, -0.52]))]
+    sun, sun_now = 0, [0]
+
+    def apply_sun(k):
+        if sun_now[0] != k:
+            vp.set_sun(suns[k], sun_power)
+            if info["est"] == vp.EST_DECOMP:
+                vp.precompute_opacity(suns[k])
+            sun_now[0] = k
     W, H = P0.width, P0.height
     bufs = [vp.DeviceBuffer(W, H), vp.DeviceBuffer(W, H)]
     ref = vp.DeviceBuffer(W, H)
@@ -318,8 +330,12 @@ def test_call_sequences_with_batches_in_flight(vp, workload, seed):
                 vp.set_lookahead(int(rng.choice([0, 8, 64, 256])))
             elif u < 0.80:
                 cur = 1 - cur
-            elif u < 0.90:
+            elif u < 0.88:
                 frame = int(rng.integers(0, 300))          # a frame jump inside a run
+            elif u < 0.94:
+                key = (int(rng.integers(0, 1 << 30)), int(rng.integers(0, 99))); vp.set_rng(rng_mode, key)
+            elif u < 0.97:
+                sun = 1 - sun; apply_sun(sun)               # the sun table (and the optical-depth table) are rebuilt
             P = vp.make_param(W, H, density=density)
             n = int(rng.choice([1, 2, 5, 12, 30, 45, 70]))
             sync = rng.random() < 0.7                       # the reference's loop synchronises after every call
@@ -327,7 +343,7 @@ def test_call_sequences_with_batches_in_flight(vp, workload, seed):
                 vp.render_kernel(bufs[cur].ptr, f, P)
                 if sync:
                     vp.synchronize()
-            segs.append((cur, cam, density, frame, n))
+            segs.append((cur, cam, density, frame, n, key, sun))
             frame += n
         got = [b.download() for b in bufs]
         l1, c1 = vp.lookahead_stats()
@@ -336,14 +352,15 @@ def test_call_sequences_with_batches_in_flight(vp, workload, seed):
         vp.set_lookahead(0)
         for i in range(2):
             ref.reset()
-            for (b, cm, dn, f0, n) in segs:
+            for (b, cm, dn, f0, n, ky, sn) in segs:
                 if b == i:
-                    vp.set_camera(cams[cm])
+                    vp.set_camera(cams[cm]); vp.set_rng(rng_mode, ky); apply_sun(sn)
                     vp.render_frames(ref.ptr, f0, n, vp.make_param(W, H, density=dn))
             assert np.array_equal(got[i], ref.download(), equal_nan=True), (workload, seed, i, segs)
     finally:
         vp.set_lookahead(vp.LOOKAHEAD_DEFAULT)
         vp.set_camera()
+        apply_sun(0)
         for b in bufs:
             b.free()
         ref.free()
