@@ -56,7 +56,7 @@ struct State
     bool        la_speculate = true;  // ... then the first batch of a run is queued beside the run's first frame (VP_LOOKAHEAD_NO_SPECULATION=1: behind it)
     int         la_div      = 2;      // ... as long as la_div times the batch (VP_LOOKAHEAD_DIV)
     int         la_run_first = 0;     // first frame of the current run of consecutive render_kernel calls
-    int         la_ramp_from = 8;     // size of the first batch of a run (VP_LOOKAHEAD_RAMP_FROM)
+    int         la_ramp_from = 32;    // size of the first batch of a run (VP_LOOKAHEAD_RAMP_FROM)
     int         la_overlap_from = 2;  // a batch of at least this many frames has its successor queued behind it on the other slot (VP_LOOKAHEAD_OVERLAP_FROM)
     struct LaSlot  // one staged batch of frames, rendered on its own stream so that two batches overlap
     {
@@ -1214,7 +1214,7 @@ void render_key(const Param* p, std::vector<unsigned char>& key)
 // render_kernel with frame look-ahead.  The reference host calls render_kernel once per frame and synchronises
 // (host.cpp:631-632); a one-frame launch is bound by its longest path (about 14 ms for 0.48 M samples, 12x off the
 // batched rate).  A sample is a pure function of (x, y, frame, scene), so when the host asks for frame f right after
-// f-1 with nothing changed, frames f..f+n-1 are rendered in ONE launch into a staging slot (n = 8, 16, ... la_max)
+// f-1 with nothing changed, frames f..f+n-1 are rendered in ONE launch into a staging slot (n = 32, 64, ... la_max)
 // and only frame f is added to the caller's accumulator; the next calls find their frame staged and
 // just add it.  Two slots are kept in flight on two streams -- the successor of a batch (twice its size, up to la_max) is queued
 // when the batch's first frame is asked for --, so the tail of one batch (its

@@ -159,7 +159,7 @@ enum { VP_TRACK_SPECTRAL = 0, VP_TRACK_SCALAR = 1, VP_TRACK_MULTI_CHANNEL = 2 };
 int vp_set_tracking(int mode);                         /* default VP_TRACK_SPECTRAL */
 /* render_kernel renders up to max_frames consecutive frames per launch when the host asks for frame f right after f-1 with
  * unchanged state, stages them, and serves the following calls from the staged frames (bit-identical to one launch per
- * frame).  The first frame of a run is rendered alone, then batches of 8, 16, ... frames, each with its
+ * frame).  The first frame of a run is rendered alone, then batches of 32, 64, ... frames, each with its
  * successor queued behind it; beyond 64 a batch is at most half of what the run has accumulated.  A setter or a camera move
  * stops the batches in flight within a fraction of a millisecond.  Default 256; 0 or 1 = one launch per call.  Env: VP_LOOKAHEAD. */
 int vp_set_lookahead(int max_frames);

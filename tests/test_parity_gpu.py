@@ -582,7 +582,7 @@ def test_render_kernel_lookahead_is_invisible(vp, oracle):
     try:
         buf, buf2 = vp.DeviceBuffer(W, H), vp.DeviceBuffer(W, H)
         ref = np.zeros((H, W, 4), np.float32)
-        # (a) 21 consecutive frames (frame 0 alone, then batches of 8 -- [1..8], [9..16], [17..24] --, each queued when the one before it is entered)
+        # (a) 21 consecutive frames (frame 0 alone, then batches of 8, the depth set above -- [1..8], [9..16], [17..24] --, each queued when the one before it is entered)
         for f in range(21):
             vp.render_kernel(buf.ptr, f, vP)
             ref, _ = osc.render_frame(oP, f, ref)
