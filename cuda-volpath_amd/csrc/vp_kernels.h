@@ -39,6 +39,9 @@
 #ifndef VP_LIGHT_MIN_WAVES
 #define VP_LIGHT_MIN_WAVES 8   // the light kernels fit 64 vector registers: two of their waves beside four of a 96-register kernel
 #endif
+#ifndef VP_PROFILE_BLOCKS
+#define VP_PROFILE_BLOCKS 0   // 1: the counting kernels also carry cycle stamps, loop statistics and block tallies (scripts/block_profile.py)
+#endif
 #ifndef VP_GLOBAL_MIN_WAVES
 #define VP_GLOBAL_MIN_WAVES 6  // achromatic global-majorant kernel: waves per SIMD its register budget is held to.  Six since the cold
                                // per-path state lives in LDS (round 4: 79 registers, no spill); with that state in registers six cost

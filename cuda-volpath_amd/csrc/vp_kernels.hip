@@ -210,7 +210,7 @@ template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool 
 // table's): 98, four waves and the helper workgroup's fifth.  Before, with everything in registers: 91-96, five waves (six cost
 // three spilled registers and lost).
 __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK,
-                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : (EST != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES)) : MIS || LDSB ? 1 : (EST == EST_GLOBAL && TRK == 0 ? VP_GLOBAL_MIN_WAVES : (TRK ? 4 : (ACH ? VP_LOCAL_MIN_WAVES : 5)))))
+                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : (EST != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES)) : MIS || LDSB ? 1 : COUNT ? 4 : (EST == EST_GLOBAL && TRK == 0 ? VP_GLOBAL_MIN_WAVES : (TRK ? 4 : (ACH ? VP_LOCAL_MIN_WAVES : 5)))))
 void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
@@ -297,12 +297,16 @@ void render_k(SceneDev S, LaunchDev L)
 
     unsigned long long c_den = 0, c_bnd = 0, c_opa = 0, c_env = 0, c_sca = 0, c_smp = 0;
     unsigned long long d_iter = 0, d_act = 0, d_outer = 0, d_shadow = 0;  // debug (lane 0 counts wave events)
-    unsigned long long t_slow = 0, t_fast = 0, t_mark = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;  // shader cycles
-    // COUNT build: how often each code block runs (wave executions) and for how many lanes -- where the lane slots go
+    // PROF: the profiling form of the counting build (-DVP_PROFILE_BLOCKS=1: `make dev DEVNAME=prof DEVFLAGS=-DVP_PROFILE_BLOCKS=1`, scripts/
+    // block_profile.py): cycle stamps of the two phases, loop statistics and the block tallies below -- 30 64-bit counters per lane that
+    // the shipped counting build (the work counters of bench.py's lookups_per_sample) does not carry, nor their spills
+    constexpr bool PROF = COUNT && VP_PROFILE_BLOCKS;
+    unsigned long long t_slow = 0, t_fast = 0, t_mark = PROF ? __builtin_amdgcn_s_memtime() : 0ull;  // shader cycles
+    // PROF build: how often each code block runs (wave executions) and for how many lanes -- where the lane slots go
     enum { B_SETUP, B_HALF, B_LOOK, B_EXIT, B_SCATTER, B_NEE, B_HG, B_BG, B_WRITE, B_REFILL, B_GSETUP, B_FETCH, B_ZERO, B_ZERO_SH, B_EXITT, B_NBLK };
     unsigned long long bw[B_NBLK] = {}, bl[B_NBLK] = {};
     auto tally = [&](int b, bool on) __attribute__((always_inline)) {
-        if (COUNT)
+        if (PROF)
         {
             unsigned long long m = __ballot(on);
             if (m) { bw[b] += 1; bl[b] += (unsigned)__popcll(m); }
@@ -321,7 +325,7 @@ void render_k(SceneDev S, LaunchDev L)
 
     for (;;)
     {
-        if (COUNT && lane == 0) d_outer++;
+        if (PROF && lane == 0) d_outer++;
         // =========================================================== slow path: events
         // The event section reads its uniforms (camera, sun, environment, queue and image descriptors: ~70 scalars that the
         // tracking loop never touches) from the kernel-argument segment afresh in every visit instead of holding them in SGPRs
@@ -414,7 +418,8 @@ void render_k(SceneDev S, LaunchDev L)
         tally(B_SCATTER, st == EV_SCATTER);
         if (!LIGHT && st == EV_SCATTER)
         {
-            if (COUNT) { c_sca++; zrun = 0; }
+            if (COUNT) c_sca++;
+            if (PROF) zrun = 0;
             t_empty = 0.0f;  // the certificate is for the unscattered camera ray only
             if (LOCAL) nsc = nsc + 1;  // num_scatters += !through, kernel.cu:2146
             // "to match passive result": post-increment count (DECOMP :2168) / i-4 (GLOBAL :1465)
@@ -875,7 +880,7 @@ ends_done:
         }
         if (__ballot(st != ST_DONE || !exhausted) == 0ull) break;  // queue drained and every lane idle
         }
-        if (COUNT) { unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) t_slow += t - t_mark; t_mark = t; }
+        if (PROF) { unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) t_slow += t - t_mark; t_mark = t; }
 
         // =========================================================== fast path: tracking
         // one segment set-up (local-majorant estimators) and one tracking step, as lambdas: the loop below runs
@@ -1047,7 +1052,7 @@ ends_done:
                     else
                     {
                         st = EV_BG;  // transmitted through the box kernel.cu:1444-1452
-                        if (COUNT) { c_xout += zrun; zrun = 0; }
+                        if (PROF) { c_xout += zrun; zrun = 0; }
                     }
                 }
                 else
@@ -1125,7 +1130,7 @@ ends_done:
                         else if (EXITC && den == 0.0f)
                         {
                             terms++;   // exit flights: a null collision in empty space
-                            if (COUNT) zrun++;
+                            if (PROF) zrun++;
                         }
                     }
                     else
@@ -1158,7 +1163,7 @@ ends_done:
                         else if (EXITC && den == 0.0f)
                         {
                             terms++;   // exit flights: a null collision in empty space
-                            if (COUNT) zrun++;
+                            if (PROF) zrun++;
                         }
                     }
                 }
@@ -1175,7 +1180,7 @@ ends_done:
             unsigned long long wm = __ballot(!active && !(st == ST_DONE && exhausted));
             unsigned nwait = (unsigned)__popcll(wm);
             if (am == 0ull || nwait >= L.wait_lanes || (nwait > 0u && iter >= (int)L.wait_iters)) break;
-            if (COUNT)
+            if (PROF)
             {
                 const unsigned long long sm = __ballot(st == ST_SHADOW);   // (a ballot under `lane == 0` would see lane 0 only)
                 if (lane == 0) { d_iter++; d_act += (unsigned)__popcll(am); d_shadow += (unsigned)__popcll(sm); }
@@ -1186,7 +1191,7 @@ ends_done:
 #pragma unroll
             for (int u = 1; u < STEPS; u++)
             {
-                if (COUNT)
+                if (PROF)
                 {
                     unsigned long long am2 = __ballot((st == ST_TRACK) || (st == ST_SHADOW) || (LOCAL && st == ST_SETUP));
                     const unsigned long long sm2 = __ballot(st == ST_SHADOW);
@@ -1199,7 +1204,7 @@ ends_done:
                 tracking_step();
             }
         }
-        if (COUNT) { unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) t_fast += t - t_mark; t_mark = t; }
+        if (PROF) { unsigned long long t = __builtin_amdgcn_s_memtime(); if (lane == 0) t_fast += t - t_mark; t_mark = t; }
     }
 
     if (COUNT)
@@ -1207,7 +1212,7 @@ ends_done:
         // wave reduction, one atomic per counter per wave
         unsigned long long vals[12] = {c_smp, c_den, c_bnd, c_opa, c_env, c_sca, d_iter, d_act, d_outer, d_shadow, t_slow, t_fast};
 #pragma unroll
-        for (int q = 0; q < 12; q++)
+        for (int q = 0; q < (PROF ? 12 : 6); q++)
         {
             unsigned long long v = vals[q];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -1230,7 +1235,7 @@ ends_done:
             }
         }
         // block tallies are wave-uniform: lane 0 adds them
-        if (lane == 0)
+        if (PROF && lane == 0)
         {
 #pragma unroll
             for (int b = 0; b < B_NBLK; b++) { atomicAdd(&L.counters[16 + 2 * b], bw[b]); atomicAdd(&L.counters[17 + 2 * b], bl[b]); }

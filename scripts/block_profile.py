@@ -2,6 +2,12 @@
    python scripts/block_profile.py c3 [FRAMES]"""
 import os, sys
 os.environ["VP_DEBUG_COUNTERS"] = "1"
+# the tallies live in the PROFILING form of the counting kernels: cd cuda-volpath_amd && make dev DEVNAME=prof DEVFLAGS=-DVP_PROFILE_BLOCKS=1
+_prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-volpath_amd", "libvolpath_hip_prof.so")
+if "VOLPATH_LIB" not in os.environ:
+    if not os.path.exists(_prof):
+        sys.exit("block_profile.py needs " + _prof + ": cd cuda-volpath_amd && make dev DEVNAME=prof DEVFLAGS=-DVP_PROFILE_BLOCKS=1")
+    os.environ["VOLPATH_LIB"] = _prof
 os.environ.setdefault("VP_COUNT_APPROACH", "1")   # tallies of what the timed launch executes (approach_k ahead of the kernel)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cuda-volpath_amd"))

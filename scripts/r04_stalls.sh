@@ -2,6 +2,7 @@
 # Round 4: what bounds render_k?  The general kernel ALONE (VP_DEBUG_ONLY_CLASS=0: incomplete images) on the given workloads:
 #   (1) block tallies + cycle stamps of the counting build (where the lane slots and the wave cycles go; shadow rays and exit
 #       flights end where the timed build ends them), with and without exit flights,
+#       (needs cuda-volpath_amd/libvolpath_hip_prof.so: make dev DEVNAME=prof DEVFLAGS=-DVP_PROFILE_BLOCKS=1)
 #   (2) rocprofv3 pc sampling if the box allows it (stochastic first, host trap second).
 # The SQ / TCC counter passes of the timed launches are part of scripts/profile_bench.sh (profiles/r04_<wl>_digest.json).
 # scripts/r04_stalls.sh "c2 c3ref c4f" [FRAMES]     (through gpurun; writes gpurun_out/r04_stalls/)
