@@ -209,8 +209,10 @@ template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool 
 // achromatic local-majorant kernels 80: six (c3ref 2398 -> 2513); the LDS-table kernel keeps its state in registers (its LDS is the
 // table's): 98, four waves and the helper workgroup's fifth.  Before, with everything in registers: 91-96, five waves (six cost
 // three spilled registers and lost).
+// (CANCEL instances of the local-majorant kernels: look-ahead batches are launched with five workgroups per CU -- vp_api.cpp -- so five
+// waves are what their registers are budgeted for: no spill.)
 __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK,
-                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : (EST != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES)) : MIS || LDSB ? 1 : COUNT ? 4 : (EST == EST_GLOBAL && TRK == 0 ? VP_GLOBAL_MIN_WAVES : (TRK ? 4 : (ACH ? VP_LOCAL_MIN_WAVES : 5)))))
+                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : (EST != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES)) : MIS || LDSB ? 1 : COUNT ? 4 : (EST == EST_GLOBAL && TRK == 0 ? VP_GLOBAL_MIN_WAVES : (TRK ? 4 : (ACH && !CANCEL ? VP_LOCAL_MIN_WAVES : 5)))))
 void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
