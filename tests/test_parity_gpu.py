@@ -717,6 +717,14 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path):
         assert line["n_gpus"] == n and line["scaling"] == "weak" and line["unit"] == "Msamples/s" and line["value"] > 0
         assert line["config"]["spp_per_step"] == 8 and set(line["roofline"]) >= {"bound", "achieved", "peak", "frac", "traffic"}
         assert set(line["per_class"]) >= {"general", "light", "misses_box"} and line["per_camera_setup_ms"] > 0
+    # the driver's contract (one JSON line) and what this repo adds to it
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in line1, k
+    assert line1["higher_is_better"] is True and line1["vs_baseline"] is None and line1["config"]["workload"].startswith("julia128") and line1["dtype"] == "f32"
+    assert line1["roofline"]["bound"] == "hbm" and line1["roofline"]["unit"] == "GB/s" and 0 < line1["roofline"]["frac"] < 1
+    cp = line1["reference_call_pattern"]     # the reference host's own loop: one render_kernel per frame, a synchronisation after each
+    assert cp["frames"] == 1200 and cp["msamples_per_s"] > 0 and cp["orbit"]["msamples_per_s"] > 0 and cp["orbit"]["first_frame_after_a_move_ms_median"] > 0
+    assert "reference_call_pattern" not in line2
     assert line2["strong"]["scaling"] == "strong" and line2["strong"]["spp_per_step"] == 4 and line2["strong"]["value"] > 0
     assert len(line2["ranks"]["kernel_ms"]) == 2
     assert np.array_equal(np.load(one), np.load(two))
