@@ -8,7 +8,7 @@ from volpath import scene
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 vp.set_device(0)
-P, info = scene.setup(wl, last_frame=N + 4)
+P, info = scene.setup(wl, last_frame=N + 4, rng_mode=int(os.environ.get("VP_PERF_RNG", vp.RNG_PHILOX)))   # (Philox2x32-10 unless VP_PERF_RNG says otherwise)
 buf = vp.DeviceBuffer(P.width, P.height)
 for f in range(4):
     vp.render_kernel(buf.ptr, f, P); vp.synchronize()
