@@ -252,7 +252,7 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
     # class by the counters (8 B per density lookup that issued a load, 2 B per bound lookup, 32 B per optical-depth lookup, 16 B
     # per environment lookup, 32 B of accumulator traffic per sample: a 16-byte staging write, read once by the reduce); a class
     # that is a per-pixel constant (the box-missing pixels always; the light class where a null collision in empty space leaves a
-    # throughput of 1 as it is) costs ONE environment lookup per pixel and launch and the 32 B per sample of the staging slot; a
+    # throughput of 1 as it is) costs ONE environment lookup per pixel and launch and its staging slot, staged once per launch; a
     # light class that is integrated (its kernel beside the general one) fetches no cells: bound lookups + one environment lookup.
     # The counting pass walks every light path, so its env / bound counts are split by the classes' sample shares.
     light_const = class_px["light"] > 0 and light_const_flag
@@ -266,11 +266,16 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
     bytes_gen = (8.0 * cper["density_loads"] + 32.0 * cper["opacity_lookups"]) * samples_rank \
         + (2.0 * max(cper["bound_lookups"] * samples_rank - bound_other * smp_m, 0.0) * (smp_g / max(smp_g + smp_l, 1.0))) \
         + (16.0 + 32.0) * smp_g
+    # (a per-pixel constant is staged ONCE per launch -- LaunchDev::const_from -- and added frame by frame by the add-kernel, which
+    # reads it once and the accumulator once: 16 B written + 16 B read + 32 B of accumulator per PIXEL and launch; VP_NO_CONST_ROWS=1
+    # stages it for every frame as before: 32 B per sample)
+    const_once = os.environ.get("VP_NO_CONST_ROWS", "0") != "1"
+    stage_const = (lambda px, smp: 64.0 * px * launches) if const_once else (lambda px, smp: 32.0 * smp)
     if light_const:
-        bytes_light = 16.0 * class_px["light"] * launches + 32.0 * smp_l
+        bytes_light = 16.0 * class_px["light"] * launches + stage_const(class_px["light"], smp_l)
     else:
         bytes_light = 2.0 * max(cper["bound_lookups"] * samples_rank - bound_other * smp_m, 0.0) * (smp_l / max(smp_g + smp_l, 1.0)) + (16.0 + 32.0) * smp_l
-    bytes_miss = 16.0 * class_px["misses_box"] * launches + 32.0 * smp_m
+    bytes_miss = 16.0 * class_px["misses_box"] * launches + stage_const(class_px["misses_box"], smp_m)
     loaded_total = bytes_gen + bytes_light + bytes_miss
     loaded_bps = loaded_total / max(samples_rank, 1.0)
     estimator_bps = bytes_per_sample(counters, loads=False)

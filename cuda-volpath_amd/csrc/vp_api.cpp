@@ -65,6 +65,7 @@ struct State
         hipStream_t stream = nullptr;
         hipEvent_t  done = nullptr;   // recorded after the batch's render
         bool        valid = false;
+        unsigned    const_from = 0;   // LaunchDev::const_from of the batch (slots whose samples are per-pixel constants, staged once in the batch's first row)
         unsigned    launched_seq = 0; // the number of the batch whose completion `done` stands for (the slot's batch_seq while no launch is under way)
         unsigned    cancel_seq = 0;   // the number of the batch of this slot that was last told to stop (la_cancel_running)
         bool        touched = false;  // a frame of this batch was handed to the caller while the batch was still running: its add-kernel
@@ -150,6 +151,8 @@ struct State
     int         last_approach = 0;            // vp_last_approach_mode
     int         last_light_const = 0;         // vp_last_light_const
     unsigned    la_launched = 0, la_cancelled = 0;   // vp_lookahead_stats
+    bool        use_const_rows = true;        // VP_NO_CONST_ROWS=1: per-pixel constants are staged for every frame, as before round 4's end
+    unsigned    last_const_from = 0;          // LaunchDev::const_from of the last staged launch (a look-ahead slot keeps it for its add-kernels)
     bool        use_approach_local = true;    // ... and approach_local_k ahead of the decomposition estimator (VP_NO_APPROACH_LOCAL=1: off)
     bool        use_approach = true;          // approach_k ahead of the global-majorant integrator (VP_NO_APPROACH=1: off)
     unsigned    approach_fshift_max = 6;      // a wave of the approach kernels = one pixel x 2^6 frames (VP_APPROACH_FRAMES_LOG2: 0 = 64 pixels of one frame)
@@ -282,6 +285,7 @@ int ensure_device()
     if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;
     if (knob("VP_NO_SUN_CLIP", 0, 1, v)) G.use_sun_clip = v == 0;
     if (knob("VP_NO_LIGHT_CONST", 0, 1, v)) G.use_light_const = v == 0;
+    if (knob("VP_NO_CONST_ROWS", 0, 1, v)) G.use_const_rows = v == 0;
     if (knob("VP_NO_APPROACH", 0, 1, v)) G.use_approach = v == 0;
     if (knob("VP_NO_APPROACH_LOCAL", 0, 1, v)) G.use_approach_local = v == 0;
     if (knob("VP_APPROACH_FRAMES_LOG2", 0, 6, v)) G.approach_fshift_max = (unsigned)v;
@@ -1017,6 +1021,15 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         }
         else
             L.stage = nullptr;
+        // per-pixel constants of the launch (the box-missing pixels; the light class where it is written by miss_fill_k) are staged once,
+        // in the launch's first row: the slots behind the general (and an integrated light) class
+        L.const_from = 0xffffffffu; L.stage_const = nullptr;
+        if (L.stage && G.use_const_rows)
+        {
+            L.const_from  = (unsigned)(G.n_general + ((G.n_light && !light_const) ? G.n_light : 0u));
+            L.stage_const = L.stage;
+        }
+        G.last_const_from = L.const_from;
         HIPCHK(hipMemsetAsync(T.queue, 0, 2 * kQueueWords * sizeof(unsigned), T.stream));
         // the brick table goes through LDS when it fits (decomposition estimator, byte table <= 64 KiB)
         const bool lds_bounds = G.use_lds_bounds && G.est == VP_EST_DECOMP && G.quant && !G.env_mis && !G.trk &&
@@ -1303,6 +1316,7 @@ int la_render_slot(int si, vp_float4* d_out, int first, int n, const Param* p, c
     if (rc) return rc;
     HIPCHK(hipEventRecord(s.done, s.stream));
     s.launched_seq = G.batch_seq[si + 1];
+    s.const_from = G.last_const_from;
     s.valid = true; s.first = first; s.count = n; s.key = key;
     return VP_OK;
 }
@@ -1349,6 +1363,7 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
         L.pixels = G.d_tiles; L.nslots = (unsigned)per_frame; L.stage_stride = (unsigned)per_frame;
         L.out = (float4*)d_out;
         L.stage = s.buf + (size_t)(frame - s.first) * per_frame;
+        L.const_from = s.const_from; L.stage_const = s.buf;
         L.nframes = 1;
         launch_reduce(L, G.stream);
         HIPCHK(hipGetLastError());

@@ -127,6 +127,12 @@ struct LaunchDev
     // hands out no more samples -- render_k asks at every chunk it takes, the approach kernels when they start.  Null = never cancelled.
     unsigned* cancel;
     unsigned  batch_id;
+    // Samples that are per-pixel CONSTANTS of a launch (the box-missing pixels always; the light class where a null collision in empty
+    // space is neutral: miss_fill_k) are staged ONCE, in the row of the launch's first frame: slots from const_from on.  reduce_stage_k
+    // adds such a sample nframes times, in the order it would add nframes staged copies: the same bits, without 2 x 16 bytes of
+    // traffic per sample for 88 % of BASELINE config 2's samples.  (Fields appended: the offsets render_k reads do not move.)
+    unsigned      const_from;    // first slot (of the rank's pixel list) whose sample is a constant of the launch; >= nslots: none
+    const float4* stage_const;   // the staging row that holds the constants (the first frame of the batch the frames come from)
 };
 
 void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,

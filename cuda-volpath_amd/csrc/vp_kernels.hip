@@ -1519,11 +1519,19 @@ __global__ __launch_bounds__(256) void reduce_stage_k(LaunchDev L)
     unsigned pix = L.pixels[slot];
     size_t   idx = (size_t)(pix & 0xffffu) + (size_t)(pix >> 16) * L.P.width;
     float4   a   = L.out[idx];
-    for (int f = 0; f < L.nframes; f++)
+    if (slot >= L.const_from)
     {
-        float4 v = L.stage[(size_t)f * L.stage_stride + slot];
-        a        = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
+        // a per-pixel constant of the launch, staged once: added frame by frame all the same (binary32: n additions, not one product)
+        const float4 v = L.stage_const[slot];
+#pragma unroll 4
+        for (int f = 0; f < L.nframes; f++) a = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
     }
+    else
+        for (int f = 0; f < L.nframes; f++)
+        {
+            float4 v = L.stage[(size_t)f * L.stage_stride + slot];
+            a        = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
+        }
     L.out[idx] = a;
 }
 
@@ -1654,7 +1662,11 @@ __global__ __launch_bounds__(256) void miss_fill_k(SceneDev S, LaunchDev L, int 
     f3     r = rad * P.brightness;
     float4 v = make_float4(fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f), fmaxf(r.z, 0.0f), 0.0f);  // heat: 0 scatters / segments
     if (L.stage)
-        for (int f = 0; f < L.nframes; f++) L.stage[(size_t)f * L.stage_stride + L.slot_base + slot] = v;
+    {
+        // (staged once where the add-kernel knows the slot for a constant: LaunchDev::const_from)
+        const int rows = (L.slot_base + slot >= L.const_from) ? 1 : L.nframes;
+        for (int f = 0; f < rows; f++) L.stage[(size_t)f * L.stage_stride + L.slot_base + slot] = v;
+    }
     else
     {
         size_t idx = (size_t)px + (size_t)py * P.width;
