@@ -499,7 +499,10 @@ def main():
             strong_alt = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, "strong", full=False, split="frames")
     call_pattern = None
     if world == 1 and not args.no_secondary:
-        call_pattern = reference_call_pattern(args.workload, args, ctx)
+        try:
+            call_pattern = reference_call_pattern(args.workload, args, ctx)
+        except Exception as e:   # a side measurement must not take the line down with it
+            call_pattern = {"error": repr(e)}
     secondary = {}
     if world == 1 and args.workload == "c2" and not args.no_secondary:
         # The workloads that do physics in every pixel, or on the reference's own streams, under the same clock as the headline
