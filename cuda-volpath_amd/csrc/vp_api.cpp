@@ -1356,8 +1356,13 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
             if (n > 1 && la_render_slot(si ^ 1, d_out, next, n, p, key)) G.la[si ^ 1].valid = false;  // best effort
         }
         // hit: add the staged frame once its batch is rendered
-        if (hipEventQuery(s.done) != hipSuccess) { (void)hipGetLastError(); s.touched = true; }
-        HIPCHK(hipStreamWaitEvent(G.stream, s.done, 0));
+        // (a batch that has completed needs no wait queued for it)
+        if (hipEventQuery(s.done) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            s.touched = true;
+            HIPCHK(hipStreamWaitEvent(G.stream, s.done, 0));
+        }
         LaunchDev L = {};
         memcpy(&L.P, p, sizeof(Param));
         L.pixels = G.d_tiles; L.nslots = (unsigned)per_frame; L.stage_stride = (unsigned)per_frame;
