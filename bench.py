@@ -12,11 +12,14 @@ the ranks (vp_tile_owner), followed (N > 1) by one RCCL reduce of the HDR accumu
 (default): spp = 1024 * N, every GPU integrates 800*600*1024 samples per step; at N = 1 this is BASELINE.json's
 configs[1] exactly.  --scaling strong: spp = 1024 whatever N (the job is fixed, the ranks share it); --scaling both
 prints the weak line with the strong measurement inside it ("strong").  Inputs are resident in HBM before the timed
-region.  Prints ONE JSON line on rank 0; at N = 1 it also carries, under "secondary", the workloads that do physics in
-every pixel or on the reference's own streams -- each with its own roofline and CPU baseline, all inside the one run the
-driver times: BASELINE configs[2] (c3), the reference's live configuration on its own sampler.h streams (c3ref_samplerh),
-and the two flagged stand-ins of configs[3] (c4s; c4f, the frame-filling cloud, at that config's 4096 spp) -- and the
-headline's own general class (the 12 % of its pixels that scatter) as "general_class_msamples_per_s".
+region.  Prints ONE JSON line on rank 0 -- the LAST line of stdout, at most LINE_LIMIT bytes (compact_line(): the driver
+keeps an 8 KB tail; round 4's 20 KB line was cut in the middle and never parsed): the contract fields, a trimmed roofline,
+the CPU baseline, the headline's own general class (the 12 % of its pixels that scatter) as
+"general_class_msamples_per_s", and -- at N = 1 -- under "secondary" one compact dict per workload that does physics in every
+pixel or on the reference's own streams, all inside the one run the driver times: BASELINE configs[2] (c3), the reference's
+live configuration on its own sampler.h streams (c3ref_samplerh), and the two flagged stand-ins of configs[3] (c4s; c4f, the
+frame-filling cloud, at that config's 4096 spp).  Everything else (per-class tables, stall buckets, lookups per sample, the
+sentences) goes to the file named by --full-out (default gpurun_out/bench_last_full.json), never to stdout.
 """
 import argparse
 import json
@@ -37,6 +40,7 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
 # bound + 1.0 environment lookups): 8*97.6 + 2*51.3 + 16*1.0 + 32.  Quoted next to this build's own figure so that a
 # workload that does more (C2's global majorant: ~525 lookups) or less work per sample is not mis-read as bandwidth.
 REFERENCE_ESTIMATOR_BYTES_PER_SAMPLE = 8 * 97.6 + 2 * 51.3 + 16 * 1.0 + 32
+LINE_LIMIT = 3072  # bytes of the final stdout line (tests/test_host_cpu.py pins it)
 WORKLOAD_CHOICES = ["c2", "c3", "c3ref", "c1", "c4s", "c4f"]
 RNG_NAMES = {"philox": "philox2x32-10", "philox7": "philox2x32-7", "samplerh": "sampler.h"}
 # what the default N = 1 line carries besides the headline: (key, workload, stream, spp per step, timed steps, CPU seconds)
@@ -107,10 +111,91 @@ def cpu_baseline(workload, seconds_hint=15.0, rng="philox7", grid=None):
             break
     dt = time.time() - t0
     return {"value": tot / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample_short": f"frames 0..{nframes - 1} of {cfg['width']}x{cfg['height']}, {tot} samples, {dt:.1f} s, {RNG_NAMES[rng]}",
             "sample": f"frames 0..{nframes - 1} of {cfg['width']}x{cfg['height']} ({tot} samples, {dt:.1f} s, "
                       f"OpenMP over rows, {RNG_NAMES[rng]} streams"
                       + ("; frames 11+ would read the optical-depth table, whose CPU precompute is not affordable here)"
                          if cfg["est"] == O.EST_DECOMP and not across_q5 else ")")}
+
+
+def _sig(x, digits=5):
+    """x to `digits` significant digits for the compact line (None, strings, ints and bools pass)."""
+    if x is None or isinstance(x, (str, bool, int)):
+        return x
+    return float(f"{float(x):.{digits}g}")
+
+
+def compact_line(full):
+    """The line the driver parses: <= LINE_LIMIT bytes whatever the run carried.  `full` is the complete record
+    (what round 4 printed); this keeps the contract fields, a trimmed roofline, the CPU baseline, the general class and one small
+    dict per secondary workload / per split / per rank list.  Pure function of `full`: tests/test_host_cpu.py runs it on the
+    committed round-4 record and on an 8-rank stub without a GPU."""
+    cfg = full.get("config", {})
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _sig(line["value"], 6), _sig(line["ms_per_step"], 6)
+    line["config"] = {k: cfg[k] for k in ("workload", "image", "spp_per_step", "samples_per_step", "estimator", "bound_brick", "rng",
+                                          "parallelism") if k in cfg}
+
+    def roof(r):
+        if not r:
+            return None
+        b = r.get("bounded_by") or ""
+        short = None if not b else ("memory_system + valu_issue (committed pmc)" if b.startswith("memory") else "valu_issue x lane_util (committed pmc)")
+        return {"bound": r["bound"], "achieved": _sig(r["achieved"]), "peak": r["peak"], "unit": r["unit"], "frac": _sig(r["frac"], 4),
+                "traffic": _sig(r.get("traffic")), "traffic_over_loaded_bytes": _sig(r.get("traffic_over_loaded_bytes"), 4),
+                "kernel": "vp::render_k", "launch_ms": _sig(r.get("launch_ms")), "launches": r.get("launches"),
+                "lane_util": _sig(r.get("lane_util"), 3), "valu_issue_frac": _sig(r.get("valu_issue_frac"), 3), "bounded_by": short,
+                "bytes_per_sample": _sig(r.get("loaded_bytes_per_sample"), 5)}
+
+    def cpu(c):
+        if not c:
+            return None
+        return {"value": _sig(c["value"], 4), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
+                "sample": (c.get("sample_short") or c.get("sample", ""))[:96]}
+
+    if "roofline" in full:
+        line["roofline"] = roof(full["roofline"])
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = cpu(full["cpu_baseline"])
+    line["general_class_msamples_per_s"] = _sig(full.get("general_class_msamples_per_s"))
+    if full.get("secondary"):
+        sec = {}
+        for key, w in full["secondary"].items():
+            r = w.get("roofline") or {}
+            c = w.get("cpu_baseline") or {}
+            sec[key] = {"value": _sig(w["value"]), "general": _sig(w.get("general_class_msamples_per_s")), "ms_per_step": _sig(w["ms_per_step"]),
+                        "steps": w["steps"], "spp": w["config"]["spp_per_step"], "frac": _sig(r.get("frac"), 3),
+                        "traffic_ratio": _sig(r.get("traffic_over_loaded_bytes"), 3), "lane_util": _sig(r.get("lane_util"), 3),
+                        "cpu": _sig(c.get("value"), 3)}
+        line["secondary"] = sec
+    if full.get("ranks"):
+        rk = full["ranks"]
+        line["ranks"] = {"kernel_ms": [_sig(v, 4) for v in rk["kernel_ms"]], "wall_s": [_sig(v, 4) for v in rk["wall_s"]],
+                         "balance_max_over_mean": _sig(rk.get("balance_max_over_mean"), 4), "collective_ranks": rk.get("collective_ranks"),
+                         "backend": rk.get("backend")}
+    if full.get("strong"):
+        st = full["strong"]
+        line["strong"] = {"value": _sig(st["value"]), "unit": st.get("unit"), "ms_per_step": _sig(st["ms_per_step"]), "scaling": "strong",
+                          "spp_per_step": st.get("spp_per_step"), "split": st.get("split"),
+                          "balance_max_over_mean": _sig((st.get("ranks") or {}).get("balance_max_over_mean"), 4),
+                          "by_split": {k: {"value": _sig(v["value"]), "ms_per_step": _sig(v["ms_per_step"]),
+                                           "balance_max_over_mean": _sig(v.get("balance_max_over_mean"), 4)}
+                                       for k, v in (st.get("by_split") or {}).items()}}
+    if full.get("reference_call_pattern") and "msamples_per_s" in full["reference_call_pattern"]:
+        cp = full["reference_call_pattern"]
+        line["call_pattern"] = {"msamples_per_s": _sig(cp["msamples_per_s"]), "orbit_msamples_per_s": _sig(cp["orbit"]["msamples_per_s"])}
+    if full.get("full"):
+        line["full"] = full["full"]
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:   # cannot happen with the fields above (an 8-rank line with four secondaries is ~2.3 KB); never print more
+        for k in ("call_pattern", "strong", "ranks", "secondary"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= LINE_LIMIT:
+                break
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
 
 
 def self_launch(args, argv):
@@ -380,6 +465,7 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
     if world > 1:
         mean_k = sum(kerns) / world
         out["ranks"] = {"wall_s": walls, "kernel_ms": kerns, "balance_max_over_mean": max(kerns) / mean_k if mean_k > 0 else None,
+                        "collective_ranks": dist.get_world_size(), "backend": dist.get_backend(),
                         "tile_deal": "vp_tile_owner: every world-th 8x8 tile of a row, rows shifted by a hash of the row index"}
     if rehearsal:
         out["config"]["parallelism"] += " (REHEARSAL: all ranks on one GPU, gloo)"
@@ -450,6 +536,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the N = 1 line")
     ap.add_argument("--secondary", default=None, help="comma-separated subset of the secondary workloads (c3,c3ref_samplerh,c4s,c4f)")
+    ap.add_argument("--call-pattern", action="store_true",
+                    help="also time the reference host's own call pattern (one render_kernel per frame; an orbiting camera): the "
+                         "interactive shell is out of scope (SURVEY section 2 rows 15-16), so this is off by default")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_last_full.json"),
+                    help="where rank 0 writes the COMPLETE record (per-class tables, stalls, lookups per sample, notes); stdout gets "
+                         "the compact line only")
     ap.add_argument("--dump-image", default=None, help="rank 0 saves the summed HDR image (.npy) -- used by tests")
     args = ap.parse_args()
 
@@ -498,7 +590,7 @@ def main():
         if args.split in ("auto", "frames") and args.spp % world == 0:
             strong_alt = run_workload(args.workload, args, ctx, args.spp, args.steps, args.warmup, "strong", full=False, split="frames")
     call_pattern = None
-    if world == 1 and not args.no_secondary:
+    if world == 1 and args.call_pattern:
         try:
             call_pattern = reference_call_pattern(args.workload, args, ctx)
         except Exception as e:   # a side measurement must not take the line down with it
@@ -554,7 +646,16 @@ def main():
             np.save(args.dump_image, image.cpu().numpy())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, rng=args.rng, grid=grid)
-        print(json.dumps(out), flush=True)
+        # the complete record to a file (never to stdout), the compact line -- <= LINE_LIMIT bytes -- as the LAST line of stdout
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.full_out)), exist_ok=True)
+            with open(args.full_out, "w") as f:
+                json.dump(out, f, indent=1)
+            out["full"] = os.path.relpath(os.path.abspath(args.full_out), ROOT)
+        except OSError as e:
+            print(f"bench.py: could not write {args.full_out}: {e}", file=sys.stderr)
+        sys.stdout.flush()
+        print(compact_line(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

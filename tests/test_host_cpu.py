@@ -167,6 +167,51 @@ def test_bench_cpu_baseline_leg_runs_for_every_estimator(host):
     assert r["kind"] == "port" and r["value"] > 0 and "frames 0..15" in r["sample"] and "not affordable" not in r["sample"]
 
 
+def test_bench_final_line_stays_under_three_kilobytes():
+    """round 4's bench line grew to 20 KB, the driver keeps an 8 KB tail, the record was `parsed: null` and the
+    round had no measured headline.  bench.compact_line() builds the line the driver parses from the complete record: run here on
+    the round-4 record as committed (four secondaries with full rooflines, the call pattern) and on the same record dressed up as
+    an 8-rank run with both strong splits -- the line must stay under 3072 bytes, parse, and still carry the contract fields, the
+    roofline fraction and the CPU baseline."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vp_bench_line", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(root, "profiles", "bench_r04_default.json")))
+    assert len(json.dumps(full)) > 8192                     # the record that broke the parse
+    ranks = {"wall_s": [1.234567891] * 8, "kernel_ms": [1234.56789123] * 8, "balance_max_over_mean": 1.0123456789,
+             "collective_ranks": 8, "backend": "nccl", "tile_deal": "x" * 200}
+    eight = dict(full, n_gpus=8, ranks=ranks, full="gpurun_out/bench_last_full.json",
+                 strong={"value": 12345.678912, "unit": "Msamples/s", "ms_per_step": 39.87654321, "scaling": "strong", "spp_per_step": 1024,
+                         "split": "frames", "ranks": ranks, "per_class": full["per_class"],
+                         "by_split": {k: {"value": 12345.678912, "ms_per_step": 39.87654321, "parallelism": "y" * 120,
+                                          "balance_max_over_mean": 1.0123456789} for k in ("tiles", "frames")}})
+    for rec in (full, eight):
+        text = bench.compact_line(rec)
+        assert len(text) < bench.LINE_LIMIT == 3072 and "\n" not in text, len(text)
+        line = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline", "general_class_msamples_per_s", "secondary"):
+            assert k in line, k
+        assert line["config"]["workload"] == "julia256_800x600_global_majorant" and line["unit"] == "Msamples/s"
+        assert abs(line["value"] - full["value"]) < 1e-4 * full["value"] and abs(line["ms_per_step"] - full["ms_per_step"]) < 1e-4 * full["ms_per_step"]
+        r = line["roofline"]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert r["kernel"] == "vp::render_k" and len(r["bounded_by"]) <= 40 and r["traffic"] > 0 and r["launch_ms"] > 0
+        assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] == "port"
+        assert set(line["secondary"]) == {"c3", "c3ref_samplerh", "c4s", "c4f"}
+        for w in line["secondary"].values():
+            assert set(w) == {"value", "general", "ms_per_step", "steps", "spp", "frac", "traffic_ratio", "lane_util", "cpu"} and w["value"] > 0
+    line8 = json.loads(bench.compact_line(eight))
+    assert len(line8["ranks"]["kernel_ms"]) == 8 and line8["ranks"]["collective_ranks"] == 8 and line8["strong"]["split"] == "frames"
+    assert set(line8["strong"]["by_split"]) == {"tiles", "frames"}
+    # a record that could not fit drops its optional blocks rather than exceed the limit
+    fat = dict(eight, secondary={f"w{i}": full["secondary"]["c4f"] for i in range(40)})
+    assert len(bench.compact_line(fat)) <= bench.LINE_LIMIT
+
+
 def test_truncated_volume_files_are_errors(host, tmp_path):
     """a short .bin / raw file must not yield a volume with an uninitialised tail (the reference returns one)."""
     import ctypes as C

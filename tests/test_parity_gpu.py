@@ -703,30 +703,38 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(tmp_path):
     bench = os.path.join(root, "bench.py")
     one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
     common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--workload", "c1"]
-    r1 = subprocess.run([sys.executable, bench, "--gpus", "1", "--spp", "8", "--dump-image", one] + common,
+    full1, full2 = str(tmp_path / "full1.json"), str(tmp_path / "full2.json")
+    r1 = subprocess.run([sys.executable, bench, "--gpus", "1", "--spp", "8", "--dump-image", one, "--full-out", full1, "--call-pattern"] + common,
                         capture_output=True, text=True, cwd=root)
     assert r1.returncode == 0, r1.stdout + r1.stderr
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["VP_BENCH_REHEARSAL"] = "1"
-    r2 = subprocess.run([sys.executable, bench, "--gpus", "2", "--spp", "4", "--scaling", "both", "--dump-image", two] + common,
+    r2 = subprocess.run([sys.executable, bench, "--gpus", "2", "--spp", "4", "--scaling", "both", "--dump-image", two, "--full-out", full2] + common,
                         capture_output=True, text=True, cwd=root, env=env)
     assert r2.returncode == 0, r2.stdout + r2.stderr
-    line1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
-    line2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
-    for line, n in ((line1, 1), (line2, 2)):
+    # the driver's contract: the LAST line of stdout is one JSON object of at most 3 KB (round 4's 20 KB line was cut by the driver's
+    # 8 KB tail and never parsed); everything else is in the --full-out file
+    for r in (r1, r2):
+        last = r.stdout.rstrip("\n").splitlines()[-1]
+        assert last.startswith("{") and len(last) <= 3072, len(last)
+    line1 = json.loads(r1.stdout.rstrip("\n").splitlines()[-1])
+    line2 = json.loads(r2.stdout.rstrip("\n").splitlines()[-1])
+    rec1, rec2 = json.load(open(full1)), json.load(open(full2))
+    for line, rec, n in ((line1, rec1, 1), (line2, rec2, 2)):
         assert line["n_gpus"] == n and line["scaling"] == "weak" and line["unit"] == "Msamples/s" and line["value"] > 0
-        assert line["config"]["spp_per_step"] == 8 and set(line["roofline"]) >= {"bound", "achieved", "peak", "frac", "traffic"}
-        assert set(line["per_class"]) >= {"general", "light", "misses_box"} and line["per_camera_setup_ms"] > 0
+        assert line["config"]["spp_per_step"] == 8 and set(line["roofline"]) >= {"bound", "achieved", "peak", "frac", "traffic", "kernel", "launch_ms"}
+        assert abs(line["value"] - rec["value"]) <= 1e-4 * rec["value"] and line["roofline"]["kernel"] == "vp::render_k"
+        assert set(rec["per_class"]) >= {"general", "light", "misses_box"} and rec["per_camera_setup_ms"] > 0
     # the driver's contract (one JSON line) and what this repo adds to it
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in line1, k
     assert line1["higher_is_better"] is True and line1["vs_baseline"] is None and line1["config"]["workload"].startswith("julia128") and line1["dtype"] == "f32"
     assert line1["roofline"]["bound"] == "hbm" and line1["roofline"]["unit"] == "GB/s" and 0 < line1["roofline"]["frac"] < 1
-    cp = line1["reference_call_pattern"]     # the reference host's own loop: one render_kernel per frame, a synchronisation after each
+    cp = rec1["reference_call_pattern"]     # (--call-pattern) the reference host's own loop: one render_kernel per frame, a synchronisation after each
     assert cp["frames"] == 1200 and cp["msamples_per_s"] > 0 and cp["orbit"]["msamples_per_s"] > 0 and cp["orbit"]["first_frame_after_a_move_ms_median"] > 0
-    assert "reference_call_pattern" not in line2
+    assert line1["call_pattern"]["msamples_per_s"] > 0 and "reference_call_pattern" not in rec2 and "call_pattern" not in line2
     assert line2["strong"]["scaling"] == "strong" and line2["strong"]["spp_per_step"] == 4 and line2["strong"]["value"] > 0
-    assert len(line2["ranks"]["kernel_ms"]) == 2
+    assert len(line2["ranks"]["kernel_ms"]) == 2 and line2["ranks"]["collective_ranks"] == 2 and line2["ranks"]["backend"] == "gloo"
     assert np.array_equal(np.load(one), np.load(two))
 
 
