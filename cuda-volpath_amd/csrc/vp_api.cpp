@@ -53,6 +53,7 @@ struct State
     int         la_max      = 256;    // most frames rendered ahead per launch; <= 1 switches the look-ahead off
     int         la_floor    = 64;     // batches up to this size are used from the start of a run; larger ones once the run is twice as long (VP_LOOKAHEAD_FLOOR)
     bool        la_habit    = false;  // the caller has been served a staged frame: it asks for consecutive frames
+    bool        la_spec_unserved = false;   // a speculative batch is out and none of its frames has been asked for yet (the habit decays)
     bool        la_speculate = true;  // ... then the first batch of a run is queued beside the run's first frame (VP_LOOKAHEAD_NO_SPECULATION=1: behind it)
     int         la_div      = 2;      // ... as long as la_div times the batch (VP_LOOKAHEAD_DIV)
     int         la_run_first = 0;     // first frame of the current run of consecutive render_kernel calls
@@ -479,9 +480,20 @@ int do_opacity(const float* dir)
     HIPCHK(hipGetLastError());
     // the integrator's copy: per voxel its clamped 2x2x2 neighbourhood, 32 bytes -- a lookup (frames > 10, more than 20 scatters:
     // 20 per sample on the frame-filling cloud) touches one cache line instead of four
-    if (!G.d_opacity_cells) HIPCHK(hipMalloc((void**)&G.d_opacity_cells, n * 8 * sizeof(float)));
-    launch_pack_f32(G.d_opacity, G.d_opacity_cells, G.S.nx, G.S.ny, G.S.nz, false, G.stream);
-    HIPCHK(hipGetLastError());
+    // (best effort, ADVICE r4: the copy is 8x the table -- 4.3 GB at 512^3, 34 GB at 1024^3.  Where it cannot be had the integrator reads
+    // the plain table, eight loads instead of two, the same bits -- like every other table of this file that is an optimisation)
+    static const bool no_cells = getenv("VP_NO_OPACITY_CELLS") && atoi(getenv("VP_NO_OPACITY_CELLS")) == 1;
+    if (no_cells && G.d_opacity_cells) { HIPCHK(hipFree(G.d_opacity_cells)); G.d_opacity_cells = nullptr; }
+    if (!G.d_opacity_cells && !no_cells && hipMalloc((void**)&G.d_opacity_cells, n * 8 * sizeof(float)) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        G.d_opacity_cells = nullptr;
+    }
+    if (G.d_opacity_cells)
+    {
+        launch_pack_f32(G.d_opacity, G.d_opacity_cells, G.S.nx, G.S.ny, G.S.nz, false, G.stream);
+        HIPCHK(hipGetLastError());
+    }
     G.S.opacity = G.d_opacity;
     G.S.opacity_cells = G.d_opacity_cells;
     return VP_OK;
@@ -1276,6 +1288,7 @@ int la_quiesce()
 {
     // every caller is about to change what batches in flight read (tables, lists, the volume): stop them and wait
     const bool any = la_cancel_running();
+    if (G.la_spec_unserved) { G.la_habit = false; G.la_spec_unserved = false; }   // speculated and nobody came: stop speculating until a real hit
     static const bool dbg = getenv("VP_DEBUG_QUIESCE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     for (auto& s : G.la)
@@ -1354,6 +1367,9 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
             while (want > G.la_floor && want > (next - G.la_run_first) / G.la_div) want >>= 1;
             int n = la_limit(next, want, per_frame, o.bytes);
             if (n > 1 && la_render_slot(si ^ 1, d_out, next, n, p, key)) G.la[si ^ 1].valid = false;  // best effort
+            // (that launch may have rebuilt a table and quiesced -- stopping THIS batch, whose frames are then not to be
+            // served: today every table key equals the running batch's, but nothing else enforces it)
+            if (!s.valid || (s.cancel_seq == s.launched_seq && s.launched_seq)) break;
         }
         // hit: add the staged frame once its batch is rendered
         // (a batch that has completed needs no wait queued for it)
@@ -1374,6 +1390,7 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
         HIPCHK(hipGetLastError());
         G.la_last = frame;
         G.la_habit = true;   // this caller asks for consecutive frames
+        G.la_spec_unserved = false;
         return VP_OK;
     }
     // miss: how far ahead?  only when this call continues the previous one
@@ -1385,6 +1402,9 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
     if (n == 1) G.la_run_first = frame;
     if (n > 1) n = std::max(la_limit(frame, n, per_frame, G.la[0].bytes), 1);
     G.la_key = key; G.la_last = frame; G.la_prev_n = n;
+    // The habit decays: a speculative batch none of whose frames was asked for -- an interactive drag: every call is frame 0
+    // of a new camera -- cost the first frame after the move 2 ms and returned nothing; no more of them until a staged frame is served again
+    if (G.la_spec_unserved) { G.la_habit = false; G.la_spec_unserved = false; }
     (void)la_cancel_running();   // (what runs ahead for frames that will not be asked for: out of this frame's way)
     G.la[0].valid = G.la[1].valid = false;
     if (n <= 1 || !per_frame || !d_out)
@@ -1396,7 +1416,11 @@ int serve_frame(vp_float4* d_out, int frame, const Param* p)
         if (G.la_habit && G.la_speculate && per_frame && d_out && n == 1)
         {
             const int m = la_limit(frame + 1, std::min(G.la_ramp_from, std::min(G.la_max, G.la_floor)), per_frame, G.la[0].bytes);
-            if (m > 1 && la_render_slot(0, d_out, frame + 1, m, p, key)) G.la[0].valid = false;   // best effort
+            if (m > 1)
+            {
+                if (la_render_slot(0, d_out, frame + 1, m, p, key)) G.la[0].valid = false;   // best effort
+                else G.la_spec_unserved = true;
+            }
         }
         return do_render(d_out, frame, 1, p);
     }
@@ -1649,7 +1673,21 @@ int vp_set_rng(int mode, uint32_t k0, uint32_t k1)
 int vp_set_exit_flights(int mode)
 {
     if (mode < 0 || mode > 2) return fail(VP_E_ARG, "exit flights: 0 off, 1 global-majorant estimator (default), 2 every estimator that has them");
+    int rc = ensure_device();   // (first: it parses VP_NO_EXIT / VP_EXIT_LOCAL, which a later call must not override -- ADVICE r4)
+    if (rc) return rc;
     G.use_exit = mode != 0; G.exit_local = mode == 2;
+    if (G.use_exit && G.have_volume && !G.d_exit && G.d_danger)
+    {
+        // switched on after a volume was initialised without the table: build it now (the header promises the three modes unconditionally)
+        if (la_quiesce()) return VP_E_NODEVICE;
+        const size_t n = (size_t)G.S.nx * G.S.ny * G.S.nz;
+        if (hipMalloc((void**)&G.d_exit, 3 * n) == hipSuccess)
+        {
+            launch_exit_table(G.d_danger, G.d_exit, G.S.nx, G.S.ny, G.S.nz, G.stream);
+            HIPCHK(hipGetLastError());
+        }
+        else { (void)hipGetLastError(); G.d_exit = nullptr; }   // none: every path walks to the box exit, same bits
+    }
     return VP_OK;
 }
 int vp_set_tracking(int mode)

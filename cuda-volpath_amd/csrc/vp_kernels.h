@@ -11,6 +11,7 @@
 #ifndef VP_MIN_WAVES
 #define VP_MIN_WAVES 1                // launch-bounds hint: waves per SIMD the register budget must allow
 #endif
+#define VP_LDS_BYTES_PER_CU (160 * 1024)   // gfx950 (MI355X_MICROARCH.md); the static_assert at render_k's cold state ties the occupancy budgets to it
 #define VP_LDS_BOUND_ENTRIES 32768     // (max,min) byte pairs staged in LDS: 64 KiB
 #ifndef VP_CHUNK
 #define VP_CHUNK 256  // samples a wave takes from a queue per atomic

@@ -68,10 +68,11 @@ struct ColdVal;
 template <class T>
 struct ColdVal<T, true>
 {
-    T* p;
-    __device__ __forceinline__ explicit ColdVal(float* q) : p(reinterpret_cast<T*>(q)) {}
-    __device__ __forceinline__ operator T() const { return *p; }
-    __device__ __forceinline__ ColdVal& operator=(T v) { *p = v; return *this; }
+    static_assert(sizeof(T) == sizeof(float), "one LDS word per lane and field");
+    float* p;   // the word is a float in LDS whatever T is: values go through __builtin_bit_cast, not through a punned pointer
+    __device__ __forceinline__ explicit ColdVal(float* q) : p(q) {}
+    __device__ __forceinline__ operator T() const { return __builtin_bit_cast(T, *p); }
+    __device__ __forceinline__ ColdVal& operator=(T v) { *p = __builtin_bit_cast(float, v); return *this; }
 };
 template <class T>
 struct ColdVal<T, false>
@@ -259,6 +260,10 @@ void render_k(SceneDev S, LaunchDev L)
     // cold state: in LDS for the plain kernels (ColdVal / ColdF3 above)
     constexpr bool COLD = !LDSB && !LIGHT;
     constexpr int  CS_  = COLD ? VP_BLOCK : 1;
+    // (the occupancy these kernels are budgeted for holds only while that many workgroups' cold state fits the CU's LDS --
+    // a workgroup is one wave per SIMD, so waves per SIMD = workgroups per CU; gfx950: 160 KiB)
+    static_assert(!COLD || (VP_GLOBAL_MIN_WAVES > VP_LOCAL_MIN_WAVES ? VP_GLOBAL_MIN_WAVES : VP_LOCAL_MIN_WAVES) * 14 * VP_BLOCK * 4 <= VP_LDS_BYTES_PER_CU,
+                  "cold per-path state: more workgroups per CU than the LDS holds -- lower VP_*_MIN_WAVES for this ARCH");
     __shared__ float cold_[COLD ? 14 : 1][CS_];
     float* const cold_p = &cold_[0][COLD ? threadIdx.x : 0];
     ColdF3<COLD, CS_>       rad(cold_p), pd(cold_p + 3 * CS_);   // radiance sum; primary direction, kept while the shadow ray is tracked
@@ -467,7 +472,8 @@ void render_k(SceneDev S, LaunchDev L)
             if (EST == EST_DECOMP && frame > 10 && nsc > 20)
             {
                 // precomputed optical depth kernel.cu:2183-2189 (quirk Q5)
-                float op = sample_float_cells(S, S.opacity_cells, ro);   // = sample_float_volume(S, S.opacity, ro), from one line
+                // from one line of the packed copy; where that copy could not be allocated (8x the table), the plain table: same bits
+                float op = S.opacity_cells ? sample_float_cells(S, S.opacity_cells, ro) : sample_float_volume(S, S.opacity, ro);
                 if (COUNT) c_opa++;
                 if (TRK)
                 {
@@ -718,9 +724,9 @@ void render_k(SceneDev S, LaunchDev L)
                         unsigned c = 0xffffffffu;
                         if (len)
                         {
-                            // (a cancelled look-ahead batch hands out nothing more: an atomic read, so that the host's write from another
-                            // stream is seen whichever XCD this wave runs on)
-                            if (lane == 0 && !(L.cancel && atomicOr(L.cancel, 0u) >= L.batch_id)) c = atomicAdd(L.queue + q_cur * VP_QUEUE_STRIDE, 1u);
+                            // (a cancelled look-ahead batch hands out nothing more: an atomic load at agent scope, so that the host's write from
+                            // another stream is seen whichever XCD this wave runs on)
+                            if (lane == 0 && !(L.cancel && __hip_atomic_load(L.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= L.batch_id)) c = atomicAdd(L.queue + q_cur * VP_QUEUE_STRIDE, 1u);
                             c = __builtin_amdgcn_readfirstlane(c);
                         }
                         if (c < cpf * fblocks)
@@ -877,7 +883,7 @@ ends_done:
         if (CANCEL && L.cancel && (visits++ & 7u) == 0u)
         {
             unsigned w = 0;
-            if (lane == 0) w = atomicOr(L.cancel, 0u);
+            if (lane == 0) w = __hip_atomic_load(L.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a load at agent scope, not a read-modify-write: ADVICE r4)
             if ((unsigned)__builtin_amdgcn_readfirstlane((int)w) >= L.batch_id) { st = ST_DONE; exhausted = true; queue_empty = true; }
         }
         if (__ballot(st != ST_DONE || !exhausted) == 0ull) break;  // queue drained and every lane idle
@@ -1698,7 +1704,7 @@ __device__ __forceinline__ bool approach_cancelled(const LaunchDev& L)
 {
     if (!L.cancel) return false;
     unsigned w = 0;
-    if ((threadIdx.x & 63u) == 0u) w = atomicOr(L.cancel, 0u);
+    if ((threadIdx.x & 63u) == 0u) w = __hip_atomic_load(L.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return (unsigned)__builtin_amdgcn_readfirstlane((int)w) >= L.batch_id;
 }
 template <class RNG>
