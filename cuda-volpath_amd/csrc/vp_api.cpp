@@ -199,7 +199,7 @@ inline State& cur() { return t_current ? *t_current : g_default; }
 constexpr size_t kMaxPendingEvents = 64;
 
 constexpr size_t kQueueWords = VP_NQUEUES * VP_QUEUE_STRIDE;  // queue heads of one launch
-constexpr size_t kCounterWords = 48;  // 6 work counters, 6 loop statistics, 11 x (wave, lane) block tallies from word 16
+constexpr size_t kCounterWords = 72;  // 6 work counters, 6 loop statistics, 15 x (wave, lane) block tallies from word 16, 3 x 8 histogram buckets from word 48
 
 int fail(int code, const char* fmt, ...)
 {
@@ -1762,6 +1762,16 @@ int vp_read_counters(vp_counters* out, int reset)
             fprintf(stderr, "[vp] block: wave executions, lanes per execution (of 64)\n");
             for (int b = 0; b < 15; b++)
                 if (h[16 + 2 * b]) fprintf(stderr, "[vp]   %-18s %14llu  %5.1f\n", names[b], h[16 + 2 * b], (double)h[17 + 2 * b] / (double)h[16 + 2 * b]);
+            static const char* hn[3] = {"scatter", "segment/ray end", "setup"};
+            for (int q = 0; q < 3; q++)
+            {
+                unsigned long long tot = 0;
+                for (int k = 0; k < 8; k++) tot += h[48 + 8 * q + k];
+                if (!tot) continue;
+                fprintf(stderr, "[vp]   executions of %-16s by lanes 1-8 .. 57-64 (%%):", hn[q]);
+                for (int k = 0; k < 8; k++) fprintf(stderr, " %5.1f", 100.0 * (double)h[48 + 8 * q + k] / (double)tot);
+                fprintf(stderr, "\n");
+            }
         }
     if (reset) HIPCHK(hipMemset(G.d_counters, 0, sizeof h));
     return VP_OK;

@@ -51,6 +51,48 @@ enum : int
     EV_HG      = 9   // sample the phase function, continue the path
 };
 
+// Perturbation profiling (round 5; scripts/r05_pad_profile.sh, profiles/r05_pad_profile.md): no per-PC sampling is to be had on this
+// pool, so the marginal cost of a code block is measured by ADDING work to it: -DVP_PAD_<BLOCK>=N puts N dependent v_fma_f32 (the
+// cheapest vector instruction: 1.06 ns per wave-instruction per SIMD at saturation) on a scratch register into that block of
+// render_k; the launch-time difference against the unpadded build, divided by the block's executions, is what one more
+// instruction there costs -- the full issue slot if the vector pipe is the bound, less if the block runs in the shadow of waits.
+// All zero in the shipped build: vp_pad<0> is empty.
+#ifndef VP_PAD_STEP
+#define VP_PAD_STEP 0
+#endif
+#ifndef VP_PAD_FETCH
+#define VP_PAD_FETCH 0
+#endif
+#ifndef VP_PAD_EOF
+#define VP_PAD_EOF 0
+#endif
+#ifndef VP_PAD_SETUP
+#define VP_PAD_SETUP 0
+#endif
+#ifndef VP_PAD_COLL
+#define VP_PAD_COLL 0
+#endif
+#ifndef VP_PAD_END
+#define VP_PAD_END 0
+#endif
+template <int N>
+__device__ __forceinline__ void vp_pad()
+{
+    if constexpr (N > 0)
+    {
+#ifdef VP_PAD_INDEPENDENT   // four independent chains: issue cost without the dependent-issue latency of one chain
+        float t0 = 1.0f, t1 = 1.0f, t2 = 1.0f, t3 = 1.0f;
+#pragma unroll
+        for (int i = 0; i < N / 4; i++)
+            asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+#else
+        float t = 1.0f;
+#pragma unroll
+        for (int i = 0; i < N; i++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(t));
+#endif
+    }
+}
+
 __device__ __forceinline__ unsigned lane_rank(unsigned long long mask)
 {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -312,11 +354,19 @@ void render_k(SceneDev S, LaunchDev L)
     // PROF build: how often each code block runs (wave executions) and for how many lanes -- where the lane slots go
     enum { B_SETUP, B_HALF, B_LOOK, B_EXIT, B_SCATTER, B_NEE, B_HG, B_BG, B_WRITE, B_REFILL, B_GSETUP, B_FETCH, B_ZERO, B_ZERO_SH, B_EXITT, B_NBLK };
     unsigned long long bw[B_NBLK] = {}, bl[B_NBLK] = {};
+    // ... and, for the three blocks a regrouping of work would have to fill (collision, end of flight, restart set-up), the HISTOGRAM of
+    // lanes per execution in eight buckets of eight lanes (round 5: profiles/experiments/r05_wavefront_break_even.md)
+    unsigned long long hist[3][8] = {};
     auto tally = [&](int b, bool on) __attribute__((always_inline)) {
         if (PROF)
         {
             unsigned long long m = __ballot(on);
-            if (m) { bw[b] += 1; bl[b] += (unsigned)__popcll(m); }
+            if (m)
+            {
+                bw[b] += 1; bl[b] += (unsigned)__popcll(m);
+                const int h = b == B_SCATTER ? 0 : b == B_EXIT ? 1 : b == B_SETUP ? 2 : -1;
+                if (h >= 0) hist[h][((unsigned)__popcll(m) - 1u) >> 3] += 1;
+            }
         }
     };
 
@@ -425,6 +475,7 @@ void render_k(SceneDev S, LaunchDev L)
         tally(B_SCATTER, st == EV_SCATTER);
         if (!LIGHT && st == EV_SCATTER)
         {
+            vp_pad<VP_PAD_COLL>();
             if (COUNT) c_sca++;
             if (PROF) zrun = 0;
             t_empty = 0.0f;  // the certificate is for the unscattered camera ray only
@@ -658,6 +709,7 @@ void render_k(SceneDev S, LaunchDev L)
 #pragma unroll 1
         for (int rep = 0; rep < 4; rep++)
         {
+            vp_pad<VP_PAD_END>();
             bool fresh = false;   // APPR: this lane took a new sample in this round, `dist` holds where approach_k left its camera ray
             // order: a path that ends here is written, its lane refilled and the new segment set up in ONE round
             // ---- ray left the medium: background() kernel.cu:1258-1267 (quirk Q11)
@@ -897,6 +949,7 @@ ends_done:
             if (LOCAL) tally(B_SETUP, st == ST_SETUP);
             if (LOCAL && st == ST_SETUP)
             {
+                vp_pad<VP_PAD_SETUP>();
                 // intersectSuperVolume kernel.cu:1626-1661 (quirks Q6, Q10): the bound is fetched before the hit test
                 float t_near, tf;
                 bool  hit = intersect_box_inv(ro, inv_rd, S, t_near, tf);
@@ -1025,11 +1078,13 @@ ends_done:
             if (st == ST_TRACK || st == ST_SHADOW)
             {
                 const bool shadow = st == ST_SHADOW;
+                vp_pad<VP_PAD_STEP>();
                 dist += -logf_(rng.next_a()) * inv_sigma;  // kernel.cu:2085 / :784
                 tally(B_EXIT, dist >= t_end || (shadow && terms == 7));
                 tally(B_LOOK, !(dist >= t_end || (shadow && terms == 7)));
                 if (dist >= t_end || (shadow && terms == 7))
                 {
+                    vp_pad<VP_PAD_EOF>();
                     if (shadow)
                     {
                         // Tr_spectral returns 1 - terminated flags (kernel.cu:807)
@@ -1065,6 +1120,7 @@ ends_done:
                 }
                 else
                 {
+                    vp_pad<VP_PAD_FETCH>();
                     f3    p   = ro + rd * dist;
                     float den;
                     tally(B_FETCH, !LIGHT && (shadow || !(dist < t_empty)));
@@ -1247,6 +1303,10 @@ ends_done:
         {
 #pragma unroll
             for (int b = 0; b < B_NBLK; b++) { atomicAdd(&L.counters[16 + 2 * b], bw[b]); atomicAdd(&L.counters[17 + 2 * b], bl[b]); }
+#pragma unroll
+            for (int h = 0; h < 3; h++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) atomicAdd(&L.counters[48 + 8 * h + q], hist[h][q]);
         }
     }
 }

@@ -917,6 +917,10 @@ static void sample_decomp(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
             float den = vol_sigma_t(S, pos, density_prime, C);
             f3 sigma_t_den    = sub3(muls(sigma_t_spectral, den), sigma_c_spectral);
             f3 sigma_s_den    = sub3(muls(sigma_s_spectral, den), sigma_c_spectral);
+            /* what-if 8 (test-only): the control component carries the medium's albedo -- sigma_s - albedo * sigma_c -- instead of being
+             * carved whole from the scattering coefficient: what quirk Q7 is NOT (the same thing when the albedo is 1) */
+            if (g_what_if & 8)
+                sigma_s_den = sub3(muls(sigma_s_spectral, den), mul3(sigma_c_spectral, mk3(P->albedo[0], P->albedo[1], P->albedo[2])));
             f3 sigma_null_den = sub3(mk3(sigma_t_prime, sigma_t_prime, sigma_t_prime), sigma_t_den);
 
             float Ps = fabsf(sigma_t_den.x * throughput.x) + fabsf(sigma_t_den.y * throughput.y) +
@@ -925,17 +929,21 @@ static void sample_decomp(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
                        fabsf(sigma_null_den.z * throughput.z);
             float c = (Ps + Pn);
             float e = rng_next_b(&rng) * c;
+            /* what-if 16 (test-only): the collision weights with the majorant the flight was SAMPLED with (the residual one while a
+             * control component is in use) instead of the total one: what quirk Q8 is NOT (the same thing wherever d_min = 0) */
+            const float inv_w = (g_what_if & 16) ? inv_sigma : inv_sigma_t;
             if (e < Ps)
             {
-                throughput = mul3(throughput, muls(sigma_s_den, inv_sigma_t * c / (Ps)));
+                throughput = mul3(throughput, muls(sigma_s_den, inv_w * c / (Ps)));
                 break;
             }
             else
-                throughput = mul3(throughput, muls(sigma_null_den, inv_sigma_t * c / Pn));
+                throughput = mul3(throughput, muls(sigma_null_den, inv_w * c / Pn));
         }
 
         through = fminf(distc, dist) >= t_far;
         num_scatters += (!through);
+        if (!through && use_decomposition) C->control_segments++;   /* collisions (real or control) in a segment with d_min > 0 */
         if (through)
         {
             cr_o = add3(cr_o, muls(cr_d, t_far));
@@ -949,6 +957,9 @@ static void sample_decomp(const vpo_scene* S, const vpo_param* P, uint32_t x, ui
             float reduction2 = (1.0f - s2) + s2 * (1.0f - P->g);
             float density_prime2 = reduction2 * density;
             float sigma_t_prime2 = max_sigma_t * density_prime2 * d_max;
+            /* what-if 4 (test-only, tests/test_oracle_cpu.py): the shadow ray on the GLOBAL majorant (volume maximum 1) instead of the
+             * local segment's d_max -- what quirk Q4 is NOT */
+            if (g_what_if & 4) sigma_t_prime2 = max_sigma_t * density_prime2 * 1.0f;
             float inv_sigma2     = 1.0f / sigma_t_prime2;
             float ph = vpo_hg_eval(phase_g, dot3(frame.n, sun_dir));
             f3    a;
@@ -1372,6 +1383,7 @@ void vpo_render_sample(const vpo_scene* S, const vpo_param* P, int x, int y, int
         C->samples += local.samples; C->density_lookups += local.density_lookups;
         C->bound_lookups += local.bound_lookups; C->opacity_lookups += local.opacity_lookups;
         C->env_lookups += local.env_lookups; C->scatters += local.scatters; C->rng_draws += local.rng_draws;
+        C->control_segments += local.control_segments;
     }
 }
 
@@ -1405,6 +1417,7 @@ void vpo_render_frame(const vpo_scene* S, const vpo_param* P, int frame, float* 
             tot.samples += loc.samples; tot.density_lookups += loc.density_lookups;
             tot.bound_lookups += loc.bound_lookups; tot.opacity_lookups += loc.opacity_lookups;
             tot.env_lookups += loc.env_lookups; tot.scatters += loc.scatters; tot.rng_draws += loc.rng_draws;
+            tot.control_segments += loc.control_segments;
         }
     }
     if (C)
@@ -1412,6 +1425,7 @@ void vpo_render_frame(const vpo_scene* S, const vpo_param* P, int frame, float* 
         C->samples += tot.samples; C->density_lookups += tot.density_lookups;
         C->bound_lookups += tot.bound_lookups; C->opacity_lookups += tot.opacity_lookups;
         C->env_lookups += tot.env_lookups; C->scatters += tot.scatters; C->rng_draws += tot.rng_draws;
+        C->control_segments += tot.control_segments;
     }
 }
 

@@ -94,6 +94,7 @@ typedef struct
     uint64_t env_lookups;
     uint64_t scatters;
     uint64_t rng_draws;
+    uint64_t control_segments;  /* A1: collisions found in a segment whose bound minimum is positive (the control component of quirk Q7 in use) */
 } vpo_counters;
 
 /* one sample per pixel of frame `frame`, accum[pix] += (rgb, heat).  rows [y0,y1).  threads<=0: all. */

@@ -46,7 +46,7 @@ class Scene(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "density_lookups", "bound_lookups", "opacity_lookups",
-                                          "env_lookups", "scatters", "rng_draws")]
+                                          "env_lookups", "scatters", "rng_draws", "control_segments")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
