@@ -219,6 +219,19 @@ __device__ __forceinline__ float lerpf(float a, float b, float w) { return a * (
 // Evaluated here in binary32 without any rounding before the last step: with weights w/256 every
 // x- and y-stage value is an integer multiple of 2^-16 below 2^8 (<= 24 significant bits, exact), and
 // the z-stage is ONE fma, so its result is the correctly rounded v / 2^24 = float(v) / 2^24.
+// the same filter on eight texels given as floats (opacity_lds_k reads them from its LDS tile): tXYZ = texel (i+X, j+Y, k+Z)
+__device__ __forceinline__ float filter_texels_u8(float t000, float t100, float t010, float t110, float t001, float t101, float t011, float t111,
+                                                  float fx, float fy, float fz)
+{
+    float x00  = fma_(t100 - t000, fx, t000);
+    float x10  = fma_(t110 - t010, fx, t010);
+    float x01  = fma_(t101 - t001, fx, t001);
+    float x11  = fma_(t111 - t011, fx, t011);
+    float y0   = fma_(x10 - x00, fy, x00);
+    float y1   = fma_(x11 - x01, fy, x01);
+    float v    = fma_(y1 - y0, fz, y0);
+    return v * (VP_U8_TRI_SCALE * 16777216.0f);
+}
 __device__ __forceinline__ float filter_cell_u8(uint2 c, float fx, float fy, float fz)
 {
     // (float)(byte k of a dword) selects v_cvt_f32_ubyte<k>

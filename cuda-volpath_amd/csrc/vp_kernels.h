@@ -168,7 +168,8 @@ void launch_reduce(const LaunchDev& L, hipStream_t st);
 // bricks: cells in 4x4x4 bricks (vp_device.h cell_index); the buffer then holds ceil(n/4)^3 * 64 cells
 void launch_pack_u8(const unsigned char* vol, uint2* cells, int nx, int ny, int nz, bool bricks, hipStream_t st);
 void launch_pack_f32(const float* vol, float* cells, int nx, int ny, int nz, bool bricks, hipStream_t st);
-void launch_opacity(const SceneDev& S, bool quant, const float dir[3], float* out, hipStream_t st);
+// lds: uchar volumes through opacity_lds_k (the density grid staged through LDS tile by tile), else opacity_k: the same bits
+void launch_opacity(const SceneDev& S, bool quant, bool lds, const float dir[3], float* out, hipStream_t st);
 void launch_build_bounds(const void* d_vol, bool quant, void* d_out, void* d_tmp_a, void* d_tmp_b, int nx, int ny, int nz, int radius, int brick,
                          hipStream_t st);
 void launch_julia(unsigned char* grid, int n, hipStream_t st);

@@ -160,6 +160,7 @@ int main(int argc, char** argv)
     volpath::NodeReducer reducer;
     std::string          rerr;
     if (!reducer.init(devices, rerr)) { fprintf(stderr, "%s\n", rerr.c_str()); return 1; }
+    if (gpus > 1) printf("multi-GPU reducer: %s\n", reducer.describe().c_str());
     use(0);
     vp_float4* disp = (vp_float4*)vp_malloc((size_t)npix * sizeof(vp_float4));
     if (!disp) { fprintf(stderr, "%s\n", vp_last_error()); return 1; }

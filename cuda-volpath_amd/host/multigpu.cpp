@@ -22,6 +22,9 @@ struct Rccl
     decltype(&ncclGroupStart)     GroupStart     = nullptr;
     decltype(&ncclGroupEnd)       GroupEnd       = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion)     GetVersion     = nullptr;   // optional: only for describe()
+    decltype(&ncclCommCount)      CommCount      = nullptr;
+    decltype(&ncclCommUserRank)   CommUserRank   = nullptr;
 } R;
 
 template <class F>
@@ -43,6 +46,9 @@ static bool load_rccl(void*& lib, std::string& err)
         err = "librccl.so.1 lacks an expected symbol";
         return false;
     }
+    (void)sym(lib, "ncclGetVersion", R.GetVersion);
+    (void)sym(lib, "ncclCommCount", R.CommCount);
+    (void)sym(lib, "ncclCommUserRank", R.CommUserRank);
     return true;
 }
 
@@ -74,7 +80,11 @@ bool rccl_selftest(int device, size_t count, std::string& report)
             break;
         }
         ok = back == h;   // the sum over one rank is the rank's own data
-        report = ok ? "ncclCommInitAll(1 rank) + ncclReduce(sum, float, " + std::to_string(count) + ") on device " + std::to_string(device) + ": ok"
+        int ver = 0, cnt = -1;
+        if (R.GetVersion) (void)R.GetVersion(&ver);
+        if (R.CommCount) (void)R.CommCount(comm, &cnt);
+        report = ok ? "RCCL " + std::to_string(ver) + ", ncclCommCount " + std::to_string(cnt) + ": ncclCommInitAll(1 rank) + ncclReduce(sum, float, " +
+                          std::to_string(count) + ") on device " + std::to_string(device) + ": ok"
                     : "ncclReduce over one rank changed the data";
     } while (false);
     if (d) (void)hipFree(d);
@@ -127,6 +137,24 @@ bool NodeReducer::reduce_to_root(const std::vector<vp_ctx*>& ctx, const std::vec
     for (size_t i = 1; i < n; i++)
         if (vp_accumulate(acc[0], acc[i], n_float4)) { err = vp_last_error(); return false; }
     return true;
+}
+
+std::string NodeReducer::describe() const
+{
+    if (comms_.empty()) return "no collective (one GPU, or contexts sharing a GPU: on-device sum)";
+    int ver = 0;
+    if (R.GetVersion) (void)R.GetVersion(&ver);
+    std::string s = "RCCL " + std::to_string(ver) + ", " + std::to_string(comms_.size()) + " communicators (ncclCommInitAll), devices";
+    for (int d : devices_) s += " " + std::to_string(d);
+    s += "; ncclCommCount/ncclCommUserRank per communicator:";
+    for (void* c : comms_)
+    {
+        int cnt = -1, rk = -1;
+        if (R.CommCount) (void)R.CommCount((ncclComm_t)c, &cnt);
+        if (R.CommUserRank) (void)R.CommUserRank((ncclComm_t)c, &rk);
+        s += " " + std::to_string(cnt) + "/" + std::to_string(rk);
+    }
+    return s;
 }
 
 void NodeReducer::shutdown()

@@ -32,6 +32,9 @@ public:
     bool reduce_to_root(const std::vector<vp_ctx*>& ctx, const std::vector<vp_float4*>& acc, const std::vector<void*>& stream,
                         size_t n_float4, std::string& err);
     bool uses_rccl() const { return !comms_.empty(); }
+    // what the first run on more than one GPU should say about itself: the RCCL version, the number of communicators, and every
+    // communicator's ncclCommCount / ncclCommUserRank (this path has never exchanged a byte between ranks)
+    std::string describe() const;
     // destroys the communicators; call it BEFORE the contexts (whose streams the collectives ran on) are destroyed
     void shutdown();
     ~NodeReducer();

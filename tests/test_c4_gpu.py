@@ -159,6 +159,13 @@ def test_cli_bin_ingest_matches_oracle_and_two_contexts_match_one(vp, oracle, tm
     assert open(out1, "rb").read() == open(out2, "rb").read()
     r3 = subprocess.run([exe] + common + ["--gpus", "3", "--devices", "0,0,0", "--batch", "2", "--out", out3], capture_output=True, text=True)
     assert r3.returncode == 0, r3.stdout + r3.stderr
+    # EIGHT ranks (BASELINE configs[4]'s shard count) as eight contexts of this one process on the one GPU: the tile deal for
+    # world = 8, eight launches side by side, the sum on the root context -- the same file byte for byte
+    out8 = str(tmp_path / "eight.ppm")
+    r8 = subprocess.run([exe] + common + ["--gpus", "8", "--devices", "0,0,0,0,0,0,0,0", "--out", out8], capture_output=True, text=True)
+    assert r8.returncode == 0, r8.stdout + r8.stderr
+    assert "8 ranks (shared device" in r8.stdout and "multi-GPU reducer: no collective" in r8.stdout, r8.stdout
+    assert open(out1, "rb").read() == open(out8, "rb").read()
     # the oracle on the same inputs
     grid = (np.clip(vol, 0, 1) * np.float32(255)).astype(np.uint8)
     nz, ny, nx = grid.shape
@@ -339,6 +346,11 @@ def test_rccl_calls_of_the_multi_gpu_host_run_on_this_gpu():
     r = subprocess.run([exe, "--rccl-selftest", "0"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ncclReduce(sum, float, 3686400) on device 0: ok" in r.stdout, r.stdout
+    #  the run describes itself: RCCL's version and the communicator's rank count, so that the first run on
+    # more than one GPU says what it ran on
+    import re
+    m = re.search(r"RCCL (\d+), ncclCommCount (\d+):", r.stdout)
+    assert m and int(m.group(1)) > 20000 and int(m.group(2)) == 1, r.stdout
 
 
 def test_torch_rccl_backend_runs_a_one_rank_reduce():

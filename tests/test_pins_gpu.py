@@ -735,3 +735,50 @@ def test_julia_interior_matches_the_references_own_screenshot_on_the_gpu(vp):
             assert r2 >= factor * rms and p2 < pear - 0.05, (medium, p2, s2, r2)
     finally:
         vp.set_camera()
+
+
+@pytest.mark.parametrize("shape,box", [((29, 22, 37), ((-1.0, -0.6, -1.3), (1.0, 0.9, 1.2))), ((8, 16, 24), None), ((3, 5, 2), None), ((64, 64, 64), None),
+                                       ((130, 17, 9), ((0.2, -0.1, 0.3), (1.7, 0.05, 0.4)))])
+def test_opacity_march_through_lds_tiles_is_the_definition_bit_for_bit(vp, shape, box):
+    """north_star's "density grid staged through LDS" where the path's rays are coherent: precompute_opacity (A10, kernel.cu:483-553)
+    marches EVERY voxel along one direction with one step, so a workgroup's 8x8x8 voxels are a rigid body moving through the grid and
+    the texels it filters over a chunk of steps are a 16^3 box -- opacity_lds_k stages that box (4 KiB, coalesced) and filters from
+    LDS.  opacity_k (one packed-cell gather per step, the kernel the oracle comparisons of test_c4_gpu.py were written against)
+    stays the definition: here both build the whole table for ragged, flat, tiny and off-centre grids, for directions along an axis,
+    against every face, grazing and steep, with both filter modes -- np.array_equal.  (The tile's position is a performance matter
+    only: a sample outside it reads the packed cell from global memory; the tiny and flat grids take that path for their clamped
+    taps, the others do not.)"""
+    import os
+    nz, ny, nx = shape
+    rs = np.random.default_rng(nx * 1000 + ny)
+    g = rs.random((nz, ny, nx), dtype=np.float32)
+    g[rs.random(g.shape) < 0.4] = 0
+    grid = np.ascontiguousarray((g * 255).astype(np.uint8))
+    dirs = [(0.0, 0.951057, -0.309017), (1.0, 0.0, 0.0), (0.0, -1.0, 0.0), (0.0, 0.0, 1.0), (-0.57735, 0.57735, -0.57735),
+            (0.999, 0.04, 0.02), (-0.3, -0.2, 0.93)]
+
+    def tables(linear):
+        out = []
+        vp.init_volume(grid, box=box, brick=1, linear=linear)
+        for d in dirs:
+            vp.precompute_opacity(d)
+            out.append(vp.opacity_table(shape))
+        return out
+
+    for linear in (True, False):
+        lds = tables(linear)
+        old = os.environ.get("VP_NO_OPACITY_LDS")
+        os.environ["VP_NO_OPACITY_LDS"] = "1"
+        ctx = vp.Context(0)
+        try:
+            with ctx:
+                ref = tables(linear)
+        finally:
+            ctx.destroy()
+            if old is None:
+                del os.environ["VP_NO_OPACITY_LDS"]
+            else:
+                os.environ["VP_NO_OPACITY_LDS"] = old
+        for d, a, b in zip(dirs, lds, ref):
+            assert np.array_equal(a, b), (linear, d, int((a != b).sum()), float(np.abs(a - b).max()))
+            assert (b > 0).any()
