@@ -103,6 +103,7 @@ struct State
     unsigned*   d_queue       = nullptr;
     unsigned long long* d_counters = nullptr;
     bool        count       = false;
+    bool        use_opacity_cells = true; // the integrator reads the optical-depth table from neighbourhood-packed cells (best effort: 8x the table)
     bool        opacity_lds = true;       // precompute_opacity stages the density grid through LDS (opacity_lds_k; VP_NO_OPACITY_LDS=1: opacity_k)
     bool        wait_lanes_set = false;   // VP_WAIT_LANES given: no per-kernel default
     unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS, setup_lanes = VP_SETUP_LANES, end_lanes = VP_END_LANES, light_wait_iters = 0;  // 0 = by estimator
@@ -288,6 +289,7 @@ int ensure_device()
     if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;
     if (knob("VP_NO_SUN_CLIP", 0, 1, v)) G.use_sun_clip = v == 0;
     if (knob("VP_NO_OPACITY_LDS", 0, 1, v)) G.opacity_lds = v == 0;
+    if (knob("VP_NO_OPACITY_CELLS", 0, 1, v)) G.use_opacity_cells = v == 0;
     if (knob("VP_NO_LIGHT_CONST", 0, 1, v)) G.use_light_const = v == 0;
     if (knob("VP_NO_CONST_ROWS", 0, 1, v)) G.use_const_rows = v == 0;
     if (knob("VP_NO_APPROACH", 0, 1, v)) G.use_approach = v == 0;
@@ -485,7 +487,7 @@ int do_opacity(const float* dir)
     // 20 per sample on the frame-filling cloud) touches one cache line instead of four
     // (best effort, ADVICE r4: the copy is 8x the table -- 4.3 GB at 512^3, 34 GB at 1024^3.  Where it cannot be had the integrator reads
     // the plain table, eight loads instead of two, the same bits -- like every other table of this file that is an optimisation)
-    static const bool no_cells = getenv("VP_NO_OPACITY_CELLS") && atoi(getenv("VP_NO_OPACITY_CELLS")) == 1;
+    const bool no_cells = !G.use_opacity_cells;   // (VP_NO_OPACITY_CELLS=1: the fall-back on purpose -- the knob test renders through it)
     if (no_cells && G.d_opacity_cells) { HIPCHK(hipFree(G.d_opacity_cells)); G.d_opacity_cells = nullptr; }
     if (!G.d_opacity_cells && !no_cells && hipMalloc((void**)&G.d_opacity_cells, n * 8 * sizeof(float)) != hipSuccess)
     {

@@ -673,6 +673,10 @@ def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
         dict(VP_NO_EXIT="1"), dict(VP_EXIT_K="1"), dict(VP_EXIT_K="40"), dict(VP_EXIT_LOCAL="1"), dict(VP_EXIT_LOCAL="1", VP_EXIT_K="2"),
         # per-pixel constants staged for every frame instead of once per launch
         dict(VP_NO_CONST_ROWS="1"), dict(VP_NO_CONST_ROWS="1", VP_NO_LIGHT_CONST="1"),
+        # round 5: the optical-depth table built by the gather kernel instead of through LDS tiles; read by the integrator from the plain
+        # table instead of the packed cells (what happens by itself where the 8x copy cannot be allocated: ADVICE r4); the chromatic
+        # kernels' wait policy pinned to the general default
+        dict(VP_NO_OPACITY_LDS="1"), dict(VP_NO_OPACITY_CELLS="1"), dict(VP_NO_OPACITY_CELLS="1", VP_NO_OPACITY_LDS="1"), dict(VP_WAIT_LANES="24"),
     ]
     for env_set in settings:
         saved = {k: os.environ.get(k) for k in env_set}
