@@ -65,7 +65,7 @@ namespace vp
 {
 // Pixel-tile deal (include/volpath.h vp_tile_owner): tile (tx, ty) belongs to rank (tx + tile_row_shift(ty)) % world, i.e.
 // within a tile row every world-th tile, rows shifted against each other by a hash of the row index.  The host lists a rank's
-// tiles (vp_api.cpp tile lists); the kernels read the list.
+// tiles (vp_tables.cpp pixel lists); the kernels read the list.
 __host__ __device__ inline unsigned tile_row_shift(unsigned ty, unsigned world) { return ((ty * 0x9E3779B1u) >> 15) % world; }
 // same values as the VP_EST_* / VP_RNG_* enums of include/volpath.h
 constexpr int EST_GLOBAL = 0, EST_DECOMP = 1, EST_BOUNDED = 2;
@@ -91,7 +91,7 @@ struct LaunchDev
     unsigned* queue;        // VP_NQUEUES sample-queue heads, VP_QUEUE_STRIDE words apart (zeroed before the launch)
     unsigned chunk_fshift;  // log2 of the frames a chunk spans (0: a chunk is VP_CHUNK pixels of one frame; 6: four pixels x 64 frames); nframes is a multiple
     unsigned q_start[VP_NQUEUES + 1];  // slot range [q_start[q], q_start[q+1]) of a frame that queue q hands out
-    unsigned long long* counters;  // work counters, loop statistics and block tallies (vp_api.cpp kCounterWords) or null
+    unsigned long long* counters;  // work counters, loop statistics and block tallies (vp_state.h kCounterWords) or null
     unsigned key0, key1;    // Philox key
     unsigned wait_lanes, wait_iters;  // inner-loop exit policy (VP_WAIT_LANES / VP_WAIT_ITERS)
     unsigned end_lanes;     // lanes that must ask for the path-end chain (environment, write, refill) before it runs in a visit (VP_END_LANES;

@@ -252,7 +252,7 @@ template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool 
 // achromatic local-majorant kernels 80: six (c3ref 2398 -> 2513); the LDS-table kernel keeps its state in registers (its LDS is the
 // table's): 98, four waves and the helper workgroup's fifth.  Before, with everything in registers: 91-96, five waves (six cost
 // three spilled registers and lost).
-// (CANCEL instances of the local-majorant kernels: look-ahead batches are launched with five workgroups per CU -- vp_api.cpp -- so five
+// (CANCEL instances of the local-majorant kernels: look-ahead batches are launched with five workgroups per CU -- vp_render.cpp -- so five
 // waves are what their registers are budgeted for: no spill.)
 __global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK,
                              (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : (EST != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES)) : MIS || LDSB ? 1 : COUNT ? 4 : (EST == EST_GLOBAL && TRK == 0 ? VP_GLOBAL_MIN_WAVES : (TRK ? 4 : (ACH && !CANCEL ? VP_LOCAL_MIN_WAVES : 5)))))
@@ -1601,7 +1601,7 @@ __global__ __launch_bounds__(256) void reduce_stage_k(LaunchDev L)
     L.out[idx] = a;
 }
 
-// ---- the pixel lists of a rank, built on the GPU (vp_api.cpp ensure_pixel_lists): a stable partition of the rank's pixels --
+// ---- the pixel lists of a rank, built on the GPU (vp_tables.cpp ensure_pixel_lists): a stable partition of the rank's pixels --
 // those of its 8x8 tiles, tile by tile (row-major tiles, row-major pixels within a tile) -- by pixel class (0 general, 1 the whole
 // chord is certified empty, 2 the camera ray misses the box; pixel table [1].y).  Padded slot s = 64 * (n-th owned tile) + 8 * row +
 // column; slots outside the image (partial edge tiles) are dropped.  Three small kernels: per-block class counts, an exclusive scan
