@@ -12,8 +12,9 @@
 namespace vph __attribute__((visibility("hidden")))
 {
 // The default context (vp_state.h)
-State               g_default;
-thread_local State* t_current = nullptr;
+State                      g_default;
+static thread_local State* t_current = nullptr;
+State& cur() { return t_current ? *t_current : g_default; }
 
 int fail(int code, const char* fmt, ...)
 {

@@ -194,9 +194,10 @@ struct State
 };
 // The default context serves every thread that never called vp_ctx_set_current: the reference host (one scene, one device,
 // kernel.cu's file-scope statics) binds Part 1 and never sees a context.
-extern State               g_default;
-extern thread_local State* t_current;
-inline State& cur() { return t_current ? *t_current : g_default; }
+// (cur() is a function of vp_context.cpp, not an inline over `extern thread_local`: a thread_local that is only DECLARED in a translation
+// unit is reached through its init wrapper, whose weak, hidden, undefined init symbol resolves to the library's load address in a shared
+// object -- the first call from another file jumped there.  Found by the GPU suite the moment the file was split.)
+State& cur();
 #define G vph::cur()
 constexpr size_t kMaxPendingEvents = 64;
 
