@@ -85,6 +85,8 @@ int ensure_device()
     if (knob("VP_CHUNK_FRAMES_LOG2", 0, 8, v)) G.chunk_fshift = (unsigned)v;
     if (knob("VP_NO_LDS_BOUNDS", 0, 1, v)) G.use_lds_bounds = v == 0;
     if (knob("VP_NO_LDS_HELPER", 0, 1, v)) G.lds_helper = v == 0;
+    if (knob("VP_NO_LDS_COMPACT", 0, 1, v)) G.use_lds_compact = v == 0;
+    if (knob("VP_LDS_COMPACT_CHROMATIC", 0, 1, v)) G.lds_compact_chromatic = v != 0;
     if (knob("VP_CELL_BRICKS", 0, 1, v)) G.cell_bricks = (int)v;
     if (knob("VP_NO_CRAWL_TABLE", 0, 1, v)) G.use_crawl_table = v == 0;
     if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;
@@ -141,6 +143,8 @@ int free_volume()
     if (G.d_opacity) HIPCHK(hipFree(G.d_opacity));
     if (G.d_opacity_cells) HIPCHK(hipFree(G.d_opacity_cells));
     G.d_opacity_cells = nullptr; G.S.opacity_cells = nullptr;
+    if (G.d_bound_codes) HIPCHK(hipFree(G.d_bound_codes));
+    G.d_bound_codes = nullptr; G.bound_codes_ok = false;
     if (G.d_danger) HIPCHK(hipFree(G.d_danger));
     G.d_danger = nullptr;
     if (G.d_sunclip) HIPCHK(hipFree(G.d_sunclip));
@@ -250,6 +254,45 @@ int do_init_volume_(const void* h_volume, vp_extent ext, bool quantized, const v
     {
         S.bounds_f32 = (const float*)G.d_bounds;
         S.cells_f32  = (const float*)G.d_cells;
+    }
+    // The compact form of the brick table (render_k<..., LDSB = 2>, vp_kernels.h LaunchDev::bound_codes): where the table fits the LDS
+    // stage and holds at most FOUR distinct (max,min) byte pairs -- a binary volume such as the Julia sets has three -- 2-bit codes
+    // into a palette: 8 KiB at 32768 bricks instead of 64, which fits beside a plain workgroup's cold per-path state.  Built on the host
+    // from one 64 KiB read-back (set-up time, with the volume); best effort: without it the 16-bit table goes through LDS as before.
+    G.bound_codes_ok = false;
+    if (quantized && G.use_lds_compact && nb <= (size_t)VP_LDS_BOUND_ENTRIES)
+    {
+        std::vector<unsigned short> tab(nb);
+        HIPCHK(hipMemcpyAsync(tab.data(), G.d_bounds, nb * 2, hipMemcpyDeviceToHost, G.stream));
+        HIPCHK(hipStreamSynchronize(G.stream));
+        unsigned short pal[4] = {0, 0, 0, 0};
+        int            npal   = 0;
+        bool           fits   = true;
+        std::vector<unsigned> codes((nb + 15) / 16 + 4, 0u);   // + padding: the LDS stage copies whole 16-byte words
+        for (size_t b = 0; b < nb && fits; b++)
+        {
+            int c = 0;
+            while (c < npal && pal[c] != tab[b]) c++;
+            if (c == npal)
+            {
+                if (npal == 4) { fits = false; break; }
+                pal[npal++] = tab[b];
+            }
+            codes[b >> 4] |= (unsigned)c << ((b & 15u) << 1);
+        }
+        if (fits)
+        {
+            const size_t bytes = (((nb + 15) / 16) * 4 + 15) / 16 * 16;
+            if (hipMalloc((void**)&G.d_bound_codes, bytes) == hipSuccess)
+            {
+                HIPCHK(hipMemcpyAsync(G.d_bound_codes, codes.data(), bytes, hipMemcpyHostToDevice, G.stream));
+                HIPCHK(hipStreamSynchronize(G.stream));   // (codes is a local)
+                G.bound_pal[0] = (unsigned)pal[0] | (unsigned)pal[1] << 16;
+                G.bound_pal[1] = (unsigned)pal[2] | (unsigned)pal[3] << 16;
+                G.bound_codes_ok = true;
+            }
+            else { (void)hipGetLastError(); G.d_bound_codes = nullptr; }
+        }
     }
     // cells with a non-empty cell in their neighbourhood: input of the certified-empty table of the global-majorant estimator
     if (G.use_empty_table && hipMalloc((void**)&G.d_danger, n) == hipSuccess)
@@ -501,6 +544,7 @@ int vp_ctx_destroy(vp_ctx* ctx)
         if (D.d_crawl) (void)hipFree(D.d_crawl);
         if (D.d_thr) (void)hipFree(D.d_thr);
         if (D.d_sunclip) (void)hipFree(D.d_sunclip);
+        if (D.d_bound_codes) (void)hipFree(D.d_bound_codes);
         if (D.d_light_flag) (void)hipFree(D.d_light_flag);
         if (D.d_tiles) (void)hipFree(D.d_tiles);
         if (D.d_tile_rows) (void)hipFree(D.d_tile_rows);

@@ -108,6 +108,11 @@ struct LaunchDev
     // Counter-based streams: approach_k (global majorant) / approach_local_k (decomposition) has walked the camera ray of every sample
     // of this launch through its certified-empty stretch already and left (distance reached, draw pairs used) / (segment origin, pairs
     // used) in the sample's staging slot; the integrator takes a new sample up from there.  0 = start as the reference does.
+    // The brick table of the decomposition estimator in its compact form (render_k<..., LDSB = 2>): where it holds at most four distinct
+    // (max,min) byte pairs -- a binary volume: three -- 2-bit codes (sixteen per word, brick order, padded to 16 bytes) and the palette
+    // (pair 0 | pair 1 << 16, pair 2 | pair 3 << 16); built with the volume (vp_context.cpp), null otherwise
+    const unsigned* bound_codes;
+    unsigned        bound_pal[2];
     uint2*   approach_aux;    // decomposition estimator: the stream's state per staging slot (the slot holds the segment origin and the distance
                               // reached in it): .x = pair index (counter-based) / sampler.h's two words
     unsigned approach;        // 1: the walk's null collisions leave the throughput at 1; 2 (global majorant): look it up by their number in thr_table
@@ -136,7 +141,9 @@ struct LaunchDev
     const float4* stage_const;   // the staging row that holds the constants (the first frame of the batch the frames come from)
 };
 
-void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
+// lds_form: how the decomposition estimator reads its brick table -- 0 global memory, 1 the 16-bit table through LDS (512-thread
+// workgroups), 2 2-bit codes into a four-entry palette through LDS (LaunchDev::bound_codes; 256-thread workgroups, plain occupancy)
+void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int lds_form, bool mis, int trk,
                    int blocks, hipStream_t st);
 // the light pixel class (spectral tracking): pixels whose camera ray meets empty cells only
 void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int blocks, hipStream_t st);

@@ -246,7 +246,7 @@ __global__ void light_identity_k(ParamDev P, int local, const unsigned* mask, un
                                // spill four or five at six waves and run as the LDS-table kernel's helper workgroups, where a fifth wave is
                                // all a SIMD has room for: they keep five
 #endif
-template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool MIS, int TRK, bool LIGHT = false, bool CANCEL = false>
+template <int EST, class RNG, bool QUANT, bool COUNT, int LDSB, bool ACH, bool MIS, int TRK, bool LIGHT = false, bool CANCEL = false>
 // Occupancy (round 4: the cold per-path state in LDS, ColdVal above; profiles/r04_kernel_resources.txt).  The achromatic
 // global-majorant kernel needs 72 registers: SEVEN waves per SIMD (C2 2541 -> 2781 Msamples/s); the chromatic one and the plain
 // achromatic local-majorant kernels 80: six (c3ref 2398 -> 2513); the LDS-table kernel keeps its state in registers (its LDS is the
@@ -254,12 +254,25 @@ template <int EST, class RNG, bool QUANT, bool COUNT, bool LDSB, bool ACH, bool 
 // three spilled registers and lost).
 // (CANCEL instances of the local-majorant kernels: look-ahead batches are launched with five workgroups per CU -- vp_render.cpp -- so five
 // waves are what their registers are budgeted for: no spill.)
-__global__ __launch_bounds__(LDSB ? VP_BLOCK_LDS : VP_BLOCK,
-                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : (EST != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES)) : MIS || LDSB ? 1 : COUNT ? 4 : (EST == EST_GLOBAL && TRK == 0 ? VP_GLOBAL_MIN_WAVES : (TRK ? 4 : (ACH && !CANCEL ? VP_LOCAL_MIN_WAVES : 5)))))
+__global__ __launch_bounds__(LDSB == 1 ? VP_BLOCK_LDS : VP_BLOCK,
+                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : (EST != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES)) : MIS || LDSB == 1 ? 1 : COUNT ? 4 : (EST == EST_GLOBAL && TRK == 0 ? VP_GLOBAL_MIN_WAVES : (TRK ? 4 : (ACH && !CANCEL ? VP_LOCAL_MIN_WAVES : 5)))))
 void render_k(SceneDev S, LaunchDev L)
 {
-    __shared__ unsigned short lds_bounds[LDSB ? VP_LDS_BOUND_ENTRIES : 1];
-    if (LDSB)
+    __shared__ unsigned short lds_bounds[LDSB == 1 ? VP_LDS_BOUND_ENTRIES : 1];
+    // LDSB == 2 (round 5): the table as 2-bit CODES into a palette of at most four distinct (max,min) pairs -- a binary volume has three:
+    // (0,0), (255,0), (255,255) -- 8 KiB instead of 64: small enough to sit BESIDE the cold per-path state of a 256-thread workgroup, so
+    // this kernel keeps the plain kernel's registers and occupancy (six / five waves per SIMD) where the 16-bit table's costs a third
+    // of both (98-102 registers, four waves and a helper workgroup)
+    __shared__ unsigned lds_codes[LDSB == 2 ? VP_LDS_BOUND_ENTRIES / 16 : 1];
+    if (LDSB == 2)
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(L.bound_codes);
+        uint4*       dst = reinterpret_cast<uint4*>(lds_codes);
+        const int    n16 = (S.bnx * S.bny * S.bnz + 63) / 64;   // 64 codes per 16 bytes; the device table is padded
+        for (int w = threadIdx.x; w < n16; w += VP_BLOCK) dst[w] = src[w];
+        __syncthreads();
+    }
+    if (LDSB == 1)
     {
         // coalesced 16-byte loads of the table, 16-byte LDS stores
         const uint4* src = reinterpret_cast<const uint4*>(S.bounds_u8);
@@ -300,11 +313,11 @@ void render_k(SceneDev S, LaunchDev L)
     int      st = ST_DONE;
     bool     exhausted = false;
     // cold state: in LDS for the plain kernels (ColdVal / ColdF3 above)
-    constexpr bool COLD = !LDSB && !LIGHT;
+    constexpr bool COLD = LDSB != 1 && !LIGHT;
     constexpr int  CS_  = COLD ? VP_BLOCK : 1;
     // (the occupancy these kernels are budgeted for holds only while that many workgroups' cold state fits the CU's LDS --
     // a workgroup is one wave per SIMD, so waves per SIMD = workgroups per CU; gfx950: 160 KiB)
-    static_assert(!COLD || (VP_GLOBAL_MIN_WAVES > VP_LOCAL_MIN_WAVES ? VP_GLOBAL_MIN_WAVES : VP_LOCAL_MIN_WAVES) * 14 * VP_BLOCK * 4 <= VP_LDS_BYTES_PER_CU,
+    static_assert(!COLD || (VP_GLOBAL_MIN_WAVES > VP_LOCAL_MIN_WAVES ? VP_GLOBAL_MIN_WAVES : VP_LOCAL_MIN_WAVES) * (14 * VP_BLOCK * 4 + (LDSB == 2 ? VP_LDS_BOUND_ENTRIES / 4 : 0)) <= VP_LDS_BYTES_PER_CU,
                   "cold per-path state: more workgroups per CU than the LDS holds -- lower VP_*_MIN_WAVES for this ARCH");
     __shared__ float cold_[COLD ? 14 : 1][CS_];
     float* const cold_p = &cold_[0][COLD ? threadIdx.x : 0];
@@ -962,7 +975,17 @@ ends_done:
                     int bi = axis_point(pl.x, S.nx) >> S.brick_shift;
                     int bj = axis_point(pl.y, S.ny) >> S.brick_shift;
                     int bk = axis_point(pl.z, S.nz) >> S.brick_shift;
-                    unsigned short v = lds_bounds[(unsigned)bi + __umul24((unsigned)S.bnx, (unsigned)bj + __umul24((unsigned)S.bny, (unsigned)bk))];
+                    const unsigned bidx = (unsigned)bi + __umul24((unsigned)S.bnx, (unsigned)bj + __umul24((unsigned)S.bny, (unsigned)bk));
+                    unsigned v;
+                    if (LDSB == 2)
+                    {
+                        // sixteen 2-bit codes per word; the palette's four byte pairs come with the launch
+                        const unsigned code = (lds_codes[bidx >> 4] >> ((bidx & 15u) << 1)) & 3u;
+                        const unsigned pal  = (code & 2u) ? L.bound_pal[1] : L.bound_pal[0];
+                        v = (code & 1u) ? pal >> 16 : pal & 0xffffu;
+                    }
+                    else
+                        v = lds_bounds[bidx];
                     bx = (float)(v & 0xffu) * VP_U8_SCALE;
                     by = (float)(v >> 8) * VP_U8_SCALE;
                 }
@@ -2307,10 +2330,18 @@ __global__ void test_density_k(SceneDev S, const float* pos, float* out, int n)
 }
 
 // ------------------------------------------------------------------ host-side launchers
-template <int EST, class RNG, bool LDSB, bool ACH, bool MIS>
+template <int EST, class RNG, int LDSB, bool ACH, bool MIS>
 static void launch_render5(const SceneDev& S, const LaunchDev& L, bool quant, bool count, int blocks, hipStream_t st)
 {
-    const dim3 blk(LDSB ? VP_BLOCK_LDS : VP_BLOCK);
+    const dim3 blk(LDSB == 1 ? VP_BLOCK_LDS : VP_BLOCK);
+    if constexpr (LDSB == 2)
+    {
+        // the compact LDS table: the timed instance only (the host sends counting launches and look-ahead batches elsewhere)
+        hipLaunchKernelGGL((render_k<EST, RNG, true, false, 2, ACH, false, 0>), dim3(blocks), blk, 0, st, S, L);
+        return;
+    }
+    else
+    {
 #ifdef VP_DEV_BUILD
     quant = true;
     if (MIS) return;
@@ -2336,6 +2367,7 @@ static void launch_render5(const SceneDev& S, const LaunchDev& L, bool quant, bo
         else hipLaunchKernelGGL((render_k<EST, RNG, false, false, false, ACH, MIS, 0>), dim3(blocks), dim3(VP_BLOCK), 0, st, S, L);
     }
 #endif
+    }
 }
 // scalar tracking builds (the reference's compiled-out SPECTRAL_TRACKING 0 / MULTI_CHANNEL 1): three-channel throughput, no
 // LDS / MIS / counting specialisations
@@ -2354,21 +2386,21 @@ static void launch_render_scalar(const SceneDev& S, const LaunchDev& L, bool qua
         else hipLaunchKernelGGL((render_k<EST, RNG, false, false, false, false, false, 2>), dim3(blocks), blk, 0, st, S, L);
     }
 }
-template <int EST, class RNG, bool LDSB>
+template <int EST, class RNG, int LDSB>
 static void launch_render3(const SceneDev& S, const LaunchDev& L, bool quant, bool count, bool ach, bool mis, int blocks, hipStream_t st)
 {
     if (mis)
     {
         // active environment sampling: the rarely used build, kept off the LDS specialisation
-        if (ach) launch_render5<EST, RNG, false, true, true>(S, L, quant, count, blocks, st);
-        else launch_render5<EST, RNG, false, false, true>(S, L, quant, count, blocks, st);
+        if (ach) launch_render5<EST, RNG, 0, true, true>(S, L, quant, count, blocks, st);
+        else launch_render5<EST, RNG, 0, false, true>(S, L, quant, count, blocks, st);
     }
     else if (ach) launch_render5<EST, RNG, LDSB, true, false>(S, L, quant, count, blocks, st);
     else launch_render5<EST, RNG, LDSB, false, false>(S, L, quant, count, blocks, st);
 }
 
 // VP_RNG_PHILOX7: the shipped configuration only (spectral tracking, passive environment)
-template <int EST, bool LDSB>
+template <int EST, int LDSB>
 static void launch_render_p7(const SceneDev& S, const LaunchDev& L, bool quant, bool count, bool ach, int blocks, hipStream_t st)
 {
     if (ach) launch_render5<EST, RngPhilox7, LDSB, true, false>(S, L, quant, count, blocks, st);
@@ -2471,9 +2503,20 @@ void launch_pixel_lists(unsigned width, unsigned height, unsigned rank, unsigned
     hipLaunchKernelGGL(pixlist_write_k, dim3(nblocks), dim3(VP_PIXLIST_BLOCK), 0, st, D, (const unsigned*)d_block_counts, (const unsigned*)d_totals, d_out);
 }
 
-void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, bool lds_bounds, bool mis, int trk,
+void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, bool count, int lds_form, bool mis, int trk,
                    int blocks, hipStream_t st)
 {
+    const bool lds_bounds = lds_form != 0;
+    // lds_form 2: the brick table as 2-bit codes beside the cold state (decomposition, uchar volume, counter-based streams, timed
+    // launches only: the host checks all of it, vp_render.cpp)
+    if (lds_form == 2 && est == EST_DECOMP && quant && !count && !mis && !trk && !L.cancel && (rng == RNG_PHILOX7 || rng == RNG_PHILOX))
+    {
+        const ParamDev& Pc = L.P;
+        const bool achc = Pc.sigma_t[0] == Pc.sigma_t[1] && Pc.sigma_t[1] == Pc.sigma_t[2] && Pc.albedo[0] == Pc.albedo[1] && Pc.albedo[1] == Pc.albedo[2];
+        if (rng == RNG_PHILOX7) launch_render_p7<EST_DECOMP, 2>(S, L, true, false, achc, blocks, st);
+        else launch_render3<EST_DECOMP, RngPhilox, 2>(S, L, true, false, achc, false, blocks, st);
+        return;
+    }
 #ifdef VP_DEV_BUILD
     // development build (make DEV=1 -> libvolpath_hip_dev.so): only the kernels of the bench workloads are compiled
     // (Philox streams, uchar volume, spectral tracking, passive environment; global-majorant and decomposition estimators)
@@ -2487,17 +2530,17 @@ void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool
         }
         if (rng == RNG_PHILOX7)
         {
-            if (est == EST_DECOMP && lds_bounds) launch_render_p7<EST_DECOMP, true>(S, L, true, count, achd, blocks, st);
-            else if (est == EST_DECOMP) launch_render_p7<EST_DECOMP, false>(S, L, true, count, achd, blocks, st);
-            else launch_render_p7<EST_GLOBAL, false>(S, L, true, count, achd, blocks, st);
+            if (est == EST_DECOMP && lds_bounds) launch_render_p7<EST_DECOMP, 1>(S, L, true, count, achd, blocks, st);
+            else if (est == EST_DECOMP) launch_render_p7<EST_DECOMP, 0>(S, L, true, count, achd, blocks, st);
+            else launch_render_p7<EST_GLOBAL, 0>(S, L, true, count, achd, blocks, st);
             return;
         }
         if (est == EST_DECOMP)
         {
-            if (lds_bounds) launch_render3<EST_DECOMP, RngPhilox, true>(S, L, true, count, achd, false, blocks, st);
-            else launch_render3<EST_DECOMP, RngPhilox, false>(S, L, true, count, achd, false, blocks, st);
+            if (lds_bounds) launch_render3<EST_DECOMP, RngPhilox, 1>(S, L, true, count, achd, false, blocks, st);
+            else launch_render3<EST_DECOMP, RngPhilox, 0>(S, L, true, count, achd, false, blocks, st);
         }
-        else launch_render3<EST_GLOBAL, RngPhilox, false>(S, L, true, count, achd, false, blocks, st);
+        else launch_render3<EST_GLOBAL, RngPhilox, 0>(S, L, true, count, achd, false, blocks, st);
         return;
     }
 #else
@@ -2516,35 +2559,35 @@ void launch_render(const SceneDev& S, const LaunchDev& L, int est, int rng, bool
     if (rng == RNG_PHILOX7)
     {
         // (mis and trk were rejected by the API for this generator)
-        if (est == EST_DECOMP && lds_bounds && quant) launch_render_p7<EST_DECOMP, true>(S, L, quant, count, ach, blocks, st);
-        else if (est == EST_DECOMP) launch_render_p7<EST_DECOMP, false>(S, L, quant, count, ach, blocks, st);
-        else if (est == EST_BOUNDED) launch_render_p7<EST_BOUNDED, false>(S, L, quant, count, ach, blocks, st);
-        else launch_render_p7<EST_GLOBAL, false>(S, L, quant, count, ach, blocks, st);
+        if (est == EST_DECOMP && lds_bounds && quant) launch_render_p7<EST_DECOMP, 1>(S, L, quant, count, ach, blocks, st);
+        else if (est == EST_DECOMP) launch_render_p7<EST_DECOMP, 0>(S, L, quant, count, ach, blocks, st);
+        else if (est == EST_BOUNDED) launch_render_p7<EST_BOUNDED, 0>(S, L, quant, count, ach, blocks, st);
+        else launch_render_p7<EST_GLOBAL, 0>(S, L, quant, count, ach, blocks, st);
         return;
     }
     if (est == EST_DECOMP)
     {
         if (lds_bounds && quant && !mis)
         {
-            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, true>(S, L, quant, count, ach, mis, blocks, st);
-            else launch_render3<EST_DECOMP, RngSamplerH, true>(S, L, quant, count, ach, mis, blocks, st);
+            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, 1>(S, L, quant, count, ach, mis, blocks, st);
+            else launch_render3<EST_DECOMP, RngSamplerH, 1>(S, L, quant, count, ach, mis, blocks, st);
         }
         else
         {
-            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, false>(S, L, quant, count, ach, mis, blocks, st);
-            else launch_render3<EST_DECOMP, RngSamplerH, false>(S, L, quant, count, ach, mis, blocks, st);
+            if (rng == RNG_PHILOX) launch_render3<EST_DECOMP, RngPhilox, 0>(S, L, quant, count, ach, mis, blocks, st);
+            else launch_render3<EST_DECOMP, RngSamplerH, 0>(S, L, quant, count, ach, mis, blocks, st);
         }
     }
     else if (est == EST_BOUNDED)
     {
         // the dead reference variant: no LDS specialisation, it is there for completeness
-        if (rng == RNG_PHILOX) launch_render3<EST_BOUNDED, RngPhilox, false>(S, L, quant, count, ach, mis, blocks, st);
-        else launch_render3<EST_BOUNDED, RngSamplerH, false>(S, L, quant, count, ach, mis, blocks, st);
+        if (rng == RNG_PHILOX) launch_render3<EST_BOUNDED, RngPhilox, 0>(S, L, quant, count, ach, mis, blocks, st);
+        else launch_render3<EST_BOUNDED, RngSamplerH, 0>(S, L, quant, count, ach, mis, blocks, st);
     }
     else
     {
-        if (rng == RNG_PHILOX) launch_render3<EST_GLOBAL, RngPhilox, false>(S, L, quant, count, ach, mis, blocks, st);
-        else launch_render3<EST_GLOBAL, RngSamplerH, false>(S, L, quant, count, ach, mis, blocks, st);
+        if (rng == RNG_PHILOX) launch_render3<EST_GLOBAL, RngPhilox, 0>(S, L, quant, count, ach, mis, blocks, st);
+        else launch_render3<EST_GLOBAL, RngSamplerH, 0>(S, L, quant, count, ach, mis, blocks, st);
     }
 #endif
 }

@@ -203,6 +203,16 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         // the brick table goes through LDS when it fits (decomposition estimator, byte table <= 64 KiB)
         const bool lds_bounds = G.use_lds_bounds && G.est == VP_EST_DECOMP && G.quant && !G.env_mis && !G.trk &&
                                 (size_t)S.bnx * S.bny * S.bnz <= (size_t)VP_LDS_BOUND_ENTRIES;
+        // ... as 2-bit codes where it has at most four distinct pairs (round 5): the plain kernel's registers and occupancy with the table
+        // in LDS.  Timed launches of the counter-based streams; counting launches and look-ahead batches keep the 16-bit form.
+        // ACHROMATIC media only: measured (profiles/experiments/r05_lds_compact_table.txt) -- C3 +2.4 % over the 16-bit table and its
+        // helper workgroup, level with the table read from global memory; the chromatic kernel (90 registers, five waves either way)
+        // is 1.7 % FASTER with four 16-bit-table waves and the helper's fifth (c4s), so it keeps them.
+        const bool ach_lds = p->sigma_t.x == p->sigma_t.y && p->sigma_t.y == p->sigma_t.z && p->albedo.x == p->albedo.y && p->albedo.y == p->albedo.z;
+        const int lds_form = !lds_bounds ? 0 : (G.bound_codes_ok && G.d_bound_codes && !G.count && !tgt && G.rng != VP_RNG_SAMPLERH &&
+                                                (ach_lds || G.lds_compact_chromatic)) ? 2 : 1;
+        L.bound_codes = lds_form == 2 ? G.d_bound_codes : nullptr;
+        L.bound_pal[0] = G.bound_pal[0]; L.bound_pal[1] = G.bound_pal[1];
         hipEvent_t e0 = get_event(), e1 = get_event();
         bool timed = e0 && e1 && hipEventRecord(e0, T.stream) == hipSuccess;
         hipError_t le = hipSuccess;
@@ -215,7 +225,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         // COUPLING (two tuning decisions that depend on each other): approach_local_k needs 47 vector registers (kernel_resources.py);
         // beside four 97-102-register LDS-table waves AND the helper's fifth 96-register wave a SIMD has 27 left, beside the four
         // alone 124.  If approach_local_k's register count or the helper's occupancy changes, re-measure the `!tgt` below.
-        const bool lds_helper = lds_bounds && G.lds_helper && G.n_general && !(G.n_light && !light_const) && !tgt;
+        const bool lds_helper = lds_form == 1 && G.lds_helper && G.n_general && !(G.n_light && !light_const) && !tgt;
         bool fork_recorded = false;
         if ((G.n_light && G.n_general && !light_const && G.light_overlap) || lds_helper)
         {
@@ -242,7 +252,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             L.chunk_fshift = (!cls && G.chunk_fshift && f % (1 << G.chunk_fshift) == 0) ? G.chunk_fshift : 0u;
             // the pixels of the class split into VP_NQUEUES bands (whole 64-pixel groups, the last band takes the rest)
             for (unsigned q = 0; q <= VP_NQUEUES; q++) L.q_start[q] = q == VP_NQUEUES ? nt : (unsigned)((unsigned long long)(nt / 64u) * q / VP_NQUEUES) * 64u;
-            const bool     ldsb = lds_bounds && !cls;
+            const bool     ldsb = lds_form == 1 && !cls;   // (the 16-bit table: 512-thread workgroups, two per CU)
             const unsigned bsz  = ldsb ? VP_BLOCK_LDS : VP_BLOCK;
             unsigned waves  = (L.total_items + 63) / 64;
             unsigned blocks = (waves + (bsz / 64) - 1) / (bsz / 64);
@@ -328,7 +338,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                 }
                 if (le == hipSuccess)
                 {
-                    launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_bounds, G.env_mis, G.trk, (int)blocks, T.stream);
+                    launch_render(S, L, G.est, G.rng, G.quant, G.count, lds_form, G.env_mis, G.trk, (int)blocks, T.stream);
                     le = hipGetLastError();
                 }
                 // The LDS-table kernel holds 2 x 64 KiB of a CU's LDS with 2 x 512 threads: four waves per SIMD, where the
@@ -342,7 +352,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                     if (!G.aux_ev[ti][1] && hipEventCreateWithFlags(&G.aux_ev[ti][1], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); G.aux_ev[ti][1] = nullptr; }
                     if (G.aux_stream[ti] && G.aux_ev[ti][1] && hipStreamWaitEvent(G.aux_stream[ti], G.aux_ev[ti][0], 0) == hipSuccess)
                     {
-                        launch_render(S, L, G.est, G.rng, G.quant, G.count, false, G.env_mis, G.trk, G.num_cu, G.aux_stream[ti]);
+                        launch_render(S, L, G.est, G.rng, G.quant, G.count, 0, G.env_mis, G.trk, G.num_cu, G.aux_stream[ti]);
                         le = hipGetLastError();
                         if (le == hipSuccess && (hipEventRecord(G.aux_ev[ti][1], G.aux_stream[ti]) != hipSuccess || hipStreamWaitEvent(T.stream, G.aux_ev[ti][1], 0) != hipSuccess))
                             le = hipGetLastError();

@@ -111,6 +111,11 @@ struct State
                                     // workgroup too many starts when the queues are empty and ends at once)
     unsigned    chunk_fshift = 0;         // VP_CHUNK_FRAMES_LOG2: a chunk = (256 >> k) pixels x (1 << k) frames (general class)
     bool        use_lds_bounds = true;
+    bool        use_lds_compact = true;   // a brick table of at most four distinct pairs goes through LDS as 2-bit codes (VP_NO_LDS_COMPACT=1: as 16-bit pairs)
+    bool        lds_compact_chromatic = false;   // ... for chromatic media too (VP_LDS_COMPACT_CHROMATIC=1: an A/B knob; measured slower)
+    unsigned*   d_bound_codes = nullptr;  // ... the codes (built with the volume), and the palette
+    unsigned    bound_pal[2] = {0, 0};
+    bool        bound_codes_ok = false;
     bool        lds_helper  = true;       // one plain workgroup per CU beside the LDS-table kernel (VP_NO_LDS_HELPER=1)
     int         cell_bricks = 0;          // packed cells in 4x4x4 bricks (VP_CELL_BRICKS=1; an A/B knob, see do_init_volume_)
     // where the restart crawl in front of the volume ends, per pixel (crawl_table_k); rebuilt when what it depends on changes

@@ -676,6 +676,8 @@ def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
         # round 5: the optical-depth table built by the gather kernel instead of through LDS tiles; read by the integrator from the plain
         # table instead of the packed cells (what happens by itself where the 8x copy cannot be allocated: ADVICE r4); the chromatic
         # kernels' wait policy pinned to the general default
+        # the brick table through LDS as 16-bit pairs instead of 2-bit codes (and with the codes for a chromatic medium too)
+        dict(VP_NO_LDS_COMPACT="1"), dict(VP_LDS_COMPACT_CHROMATIC="1"), dict(VP_NO_LDS_COMPACT="1", VP_NO_LDS_HELPER="1"),
         dict(VP_NO_OPACITY_LDS="1"), dict(VP_NO_OPACITY_CELLS="1"), dict(VP_NO_OPACITY_CELLS="1", VP_NO_OPACITY_LDS="1"), dict(VP_WAIT_LANES="24"),
     ]
     for env_set in settings:
