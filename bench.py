@@ -75,10 +75,14 @@ def effective_cores():
     return max(1, n)
 
 
-def cpu_baseline(workload, seconds_hint=15.0, rng="philox7", grid=None):
+def cpu_baseline(workload, seconds_hint=15.0, rng="philox7", grid=None, opacity=None):
     """The oracle (CPU restatement, 'port') on this host's cores, on a bounded sample of the same workload.
     grid: the workload's uchar volume if the caller holds it already (the GPU leg's: the two voxelisers are tested bit for bit
-    against each other); else the oracle voxelises it itself."""
+    against each other); else the oracle voxelises it itself.
+    opacity: the optical-depth table the GPU leg built for this scene (precompute_opacity: an INPUT of the frames from 11 on, quirk
+    Q5; its CPU precompute is an N^4 march, minutes at 256^3 and above, and not part of the metric -- host.cpp:634-638 times the render
+    loop).  The GPU table is the oracle's own, bit for bit (tests/test_c4_gpu.py: 4152 voxels x 3 directions at 256^3 and 512^3),
+    so with it the CPU sample runs across the frame-11 switch on every workload, as the GPU job does."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from volpath import scene as vscene
@@ -98,24 +102,33 @@ def cpu_baseline(workload, seconds_hint=15.0, rng="philox7", grid=None):
     # the live kernel reads the optical-depth volume from frame 11 on (quirk Q5).  Its CPU precompute is an N^4 march
     # (minutes at 256^3 and above), so the timed sample stays within frames 0..10 there and says so; at 128^3 the table is
     # built (untimed) and the sample runs across the switch.
-    across_q5 = cfg["est"] == O.EST_DECOMP and cfg["n"] <= 128
-    if across_q5:
+    across_q5 = cfg["est"] == O.EST_DECOMP and (cfg["n"] <= 128 or opacity is not None)
+    if across_q5 and opacity is not None:
+        import numpy as np
+        osc.opacity = np.ascontiguousarray(opacity, np.float32)
+        osc.S.opacity = osc.opacity.ctypes.data
+    elif across_q5:
         osc.precompute_opacity()
     max_frames = 16 if (cfg["est"] != O.EST_DECOMP or across_q5) else 11
+    # decomposition workloads with the table: start at frame 10, so that a bounded sample of a few frames (the cloud: two seconds each on
+    # 16 cores) has both estimators in it: frame 10 is the last one that tracks every shadow ray, 11 the first that reads the table
+    first_frame = 10 if (cfg["est"] == O.EST_DECOMP and across_q5 and cfg["n"] > 128) else 0
     nframes, acc, tot, t0 = 0, None, 0, time.time()
     while True:
-        acc, c = osc.render_frame(P, nframes, acc, threads=cores)
+        acc, c = osc.render_frame(P, first_frame + nframes, acc, threads=cores)
         tot += c.samples
         nframes += 1
-        if time.time() - t0 > seconds_hint or nframes >= max_frames:
+        if time.time() - t0 > seconds_hint or first_frame + nframes >= max_frames:
             break
     dt = time.time() - t0
+    f0, f1 = first_frame, first_frame + nframes - 1
     return {"value": tot / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample_short": f"frames 0..{nframes - 1} of {cfg['width']}x{cfg['height']}, {tot} samples, {dt:.1f} s, {RNG_NAMES[rng]}",
-            "sample": f"frames 0..{nframes - 1} of {cfg['width']}x{cfg['height']} ({tot} samples, {dt:.1f} s, "
+            "sample_short": f"frames {f0}..{f1} of {cfg['width']}x{cfg['height']}, {tot} samples, {dt:.1f} s, {RNG_NAMES[rng]}",
+            "sample": f"frames {f0}..{f1} of {cfg['width']}x{cfg['height']} ({tot} samples, {dt:.1f} s, "
                       f"OpenMP over rows, {RNG_NAMES[rng]} streams"
                       + ("; frames 11+ would read the optical-depth table, whose CPU precompute is not affordable here)"
-                         if cfg["est"] == O.EST_DECOMP and not across_q5 else ")")}
+                         if cfg["est"] == O.EST_DECOMP and not across_q5 else
+                         ("; the optical-depth table read from frame 11 on is the GPU leg's, the oracle's own bit for bit)" if opacity is not None and cfg["est"] == O.EST_DECOMP else ")"))}
 
 
 def _sig(x, digits=5):
@@ -471,6 +484,8 @@ def run_workload(workload, args, ctx, spp_per_gpu, steps, warmup, scaling, full=
         out["config"]["parallelism"] += " (REHEARSAL: all ranks on one GPU, gloo)"
     out["_image"] = image
     out["_grid"] = info.get("grid")
+    # (for the CPU baseline of a decomposition workload: the optical-depth table of this scene, read back while the scene is current)
+    out["_opacity"] = vp.opacity_table((info["n"],) * 3) if (info["est"] == vp.EST_DECOMP and ctx.get("want_opacity")) else None
     return out
 
 
@@ -574,7 +589,8 @@ def main():
     vp.set_device(local_rank)
     stream = torch.cuda.Stream(device=dev)
     vp.set_stream(stream.cuda_stream)
-    ctx = {"rank": rank, "world": world, "dev": dev, "stream": stream, "rehearsal": rehearsal}
+    ctx = {"rank": rank, "world": world, "dev": dev, "stream": stream, "rehearsal": rehearsal,
+           "want_opacity": world == 1 and not args.no_cpu_baseline}
 
     if args.scaling == "auto":
         args.scaling = "both" if world > 1 else "weak"
@@ -607,10 +623,10 @@ def main():
                 continue
             sec = run_workload(wl, args, ctx, spp, min(steps, max(args.steps, 1)), 1, "weak", full=True, rng=rng, warmup_spp=64)
             sec.pop("_image")
-            grid = sec.pop("_grid")
+            grid, opa = sec.pop("_grid"), sec.pop("_opacity")
             if not args.no_cpu_baseline:
-                sec["cpu_baseline"] = cpu_baseline(wl, seconds_hint=cpu_s, rng=rng, grid=grid)
-            del grid
+                sec["cpu_baseline"] = cpu_baseline(wl, seconds_hint=cpu_s, rng=rng, grid=grid, opacity=opa)
+            del grid, opa
             secondary[key] = sec
         if "c3" in secondary:
             secondary["c3"]["note"] = ("BASELINE configs[2]: 8^3 bricks staged through LDS as the config asks (+2-3 % over the same brick table "
@@ -623,7 +639,7 @@ def main():
 
     if rank == 0:
         image = out.pop("_image")
-        grid = out.pop("_grid")
+        grid, opa = out.pop("_grid"), out.pop("_opacity")
         if strong:
             both = {"tiles": strong}
             if strong_alt:
@@ -631,6 +647,7 @@ def main():
             for q in both.values():
                 q.pop("_image")
                 q.pop("_grid")
+                q.pop("_opacity", None)
             best = max(both, key=lambda k: both[k]["value"]) if args.split == "auto" else ("frames" if (args.split == "frames" and strong_alt) else "tiles")
             out["strong"] = {k: both[best][k] for k in ("value", "unit", "ms_per_step", "scaling", "per_class", "ranks") if k in both[best]}
             out["strong"]["spp_per_step"] = both[best]["config"]["spp_per_step"]
@@ -645,7 +662,7 @@ def main():
             import numpy as np
             np.save(args.dump_image, image.cpu().numpy())
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, rng=args.rng, grid=grid)
+            out["cpu_baseline"] = cpu_baseline(args.workload, rng=args.rng, grid=grid, opacity=opa)
         # the complete record to a file (never to stdout), the compact line -- <= LINE_LIMIT bytes -- as the LAST line of stdout
         try:
             os.makedirs(os.path.dirname(os.path.abspath(args.full_out)), exist_ok=True)
