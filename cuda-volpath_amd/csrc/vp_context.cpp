@@ -141,8 +141,8 @@ int free_volume()
     if (G.d_cells) HIPCHK(hipFree(G.d_cells));
     if (G.d_bounds) HIPCHK(hipFree(G.d_bounds));
     if (G.d_opacity) HIPCHK(hipFree(G.d_opacity));
-    if (G.d_opacity_cells) HIPCHK(hipFree(G.d_opacity_cells));
-    G.d_opacity_cells = nullptr; G.S.opacity_cells = nullptr;
+    if (G.d_opacity_cells) { if (G.opacity_cells_on_host) HIPCHK(hipHostFree(G.h_opacity_cells)); else HIPCHK(hipFree(G.d_opacity_cells)); }
+    G.d_opacity_cells = nullptr; G.h_opacity_cells = nullptr; G.S.opacity_cells = nullptr; G.opacity_cells_on_host = false;
     if (G.d_bound_codes) HIPCHK(hipFree(G.d_bound_codes));
     G.d_bound_codes = nullptr; G.bound_codes_ok = false;
     if (G.d_danger) HIPCHK(hipFree(G.d_danger));

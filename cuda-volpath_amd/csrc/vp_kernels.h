@@ -111,8 +111,7 @@ struct LaunchDev
     // The brick table of the decomposition estimator in its compact form (render_k<..., LDSB = 2>): where it holds at most four distinct
     // (max,min) byte pairs -- a binary volume: three -- 2-bit codes (sixteen per word, brick order, padded to 16 bytes) and the palette
     // (pair 0 | pair 1 << 16, pair 2 | pair 3 << 16); built with the volume (vp_context.cpp), null otherwise
-    const unsigned* bound_codes;
-    unsigned        bound_pal[2];
+    // (the fields themselves: at the END of this struct -- appended, so that the offsets the other kernels read do not move)
     uint2*   approach_aux;    // decomposition estimator: the stream's state per staging slot (the slot holds the segment origin and the distance
                               // reached in it): .x = pair index (counter-based) / sampler.h's two words
     unsigned approach;        // 1: the walk's null collisions leave the throughput at 1; 2 (global majorant): look it up by their number in thr_table
@@ -139,6 +138,8 @@ struct LaunchDev
     // traffic per sample for 88 % of BASELINE config 2's samples.  (Fields appended: the offsets render_k reads do not move.)
     unsigned      const_from;    // first slot (of the rank's pixel list) whose sample is a constant of the launch; >= nslots: none
     const float4* stage_const;   // the staging row that holds the constants (the first frame of the batch the frames come from)
+    const unsigned* bound_codes;   // the compact brick table (above): 2-bit codes ...
+    unsigned        bound_pal[2];  // ... and the palette
 };
 
 // lds_form: how the decomposition estimator reads its brick table -- 0 global memory, 1 the 16-bit table through LDS (512-thread

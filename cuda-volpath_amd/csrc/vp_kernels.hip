@@ -536,8 +536,8 @@ void render_k(SceneDev S, LaunchDev L)
             if (EST == EST_DECOMP && frame > 10 && nsc > 20)
             {
                 // precomputed optical depth kernel.cu:2183-2189 (quirk Q5)
-                // from one line of the packed copy; where that copy could not be allocated (8x the table), the plain table: same bits
-                float op = S.opacity_cells ? sample_float_cells(S, S.opacity_cells, ro) : sample_float_volume(S, S.opacity, ro);
+                // (the packed copy always exists: where the device could not hold it -- 8x the table -- it lies in pinned host memory)
+                float op = sample_float_cells(S, S.opacity_cells, ro);   // = sample_float_volume(S, S.opacity, ro), from one line of the packed copy
                 if (COUNT) c_opa++;
                 if (TRK)
                 {

@@ -102,7 +102,9 @@ struct State
     unsigned*   d_queue       = nullptr;
     unsigned long long* d_counters = nullptr;
     bool        count       = false;
-    bool        use_opacity_cells = true; // the integrator reads the optical-depth table from neighbourhood-packed cells (best effort: 8x the table)
+    bool        use_opacity_cells = true; // the packed copy of the optical-depth table lives on the device (VP_NO_OPACITY_CELLS=1: in pinned host memory, the out-of-memory fall-back)
+    bool        opacity_cells_on_host = false;
+    void*       h_opacity_cells = nullptr;   // its host address (hipHostFree wants that one)
     bool        opacity_lds = true;       // precompute_opacity stages the density grid through LDS (opacity_lds_k; VP_NO_OPACITY_LDS=1: opacity_k)
     bool        wait_lanes_set = false;   // VP_WAIT_LANES given: no per-kernel default
     unsigned    wait_lanes  = VP_WAIT_LANES, wait_iters = VP_WAIT_ITERS, setup_lanes = VP_SETUP_LANES, end_lanes = VP_END_LANES, light_wait_iters = 0;  // 0 = by estimator

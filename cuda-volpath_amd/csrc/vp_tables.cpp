@@ -17,20 +17,45 @@ int do_opacity(const float* dir)
     HIPCHK(hipGetLastError());
     // the integrator's copy: per voxel its clamped 2x2x2 neighbourhood, 32 bytes -- a lookup (frames > 10, more than 20 scatters:
     // 20 per sample on the frame-filling cloud) touches one cache line instead of four
-    // (best effort, ADVICE r4: the copy is 8x the table -- 4.3 GB at 512^3, 34 GB at 1024^3.  Where it cannot be had the integrator reads
-    // the plain table, eight loads instead of two, the same bits -- like every other table of this file that is an optimisation)
-    const bool no_cells = !G.use_opacity_cells;   // (VP_NO_OPACITY_CELLS=1: the fall-back on purpose -- the knob test renders through it)
-    if (no_cells && G.d_opacity_cells) { HIPCHK(hipFree(G.d_opacity_cells)); G.d_opacity_cells = nullptr; }
-    if (!G.d_opacity_cells && !no_cells && hipMalloc((void**)&G.d_opacity_cells, n * 8 * sizeof(float)) != hipSuccess)
+    // the copy is 8x the table -- 4.3 GB at 512^3, 34 GB at 1024^3.  Where the device cannot hold it, it goes to PINNED HOST
+    // memory and the integrator reads it across the bus: the same kernel, the same bits, slow -- but precompute_opacity succeeds where
+    // it did before the copy existed, and the frames from 11 on can be rendered.  (A branch to the plain table inside render_k was built
+    // first: same bits, and 1.0-1.5 % off EVERY chromatic launch whatever its form -- per-lane, wave-uniform, out of line:
+    // profiles/experiments/r05_opacity_fallback.txt.  A fall-back must not tax the path that does not need it.)
+    // VP_NO_OPACITY_CELLS=1 takes the host copy on purpose: the knob test renders through it.
+    const size_t cbytes = n * 8 * sizeof(float);
+    if (G.d_opacity_cells && (G.opacity_cells_on_host != !G.use_opacity_cells))
     {
-        (void)hipGetLastError();
-        G.d_opacity_cells = nullptr;
+        if (G.opacity_cells_on_host) HIPCHK(hipHostFree(G.h_opacity_cells)); else HIPCHK(hipFree(G.d_opacity_cells));
+        G.d_opacity_cells = nullptr; G.h_opacity_cells = nullptr;
     }
-    if (G.d_opacity_cells)
+    if (!G.d_opacity_cells)
     {
-        launch_pack_f32(G.d_opacity, G.d_opacity_cells, G.S.nx, G.S.ny, G.S.nz, false, G.stream);
-        HIPCHK(hipGetLastError());
+        G.opacity_cells_on_host = !G.use_opacity_cells;
+        if (G.use_opacity_cells && hipMalloc((void**)&G.d_opacity_cells, cbytes) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            G.d_opacity_cells = nullptr;
+            G.opacity_cells_on_host = true;
+        }
+        if (!G.d_opacity_cells)
+        {
+            void* h = nullptr;
+            if (hipHostMalloc(&h, cbytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                return fail(VP_E_NOMEM, "no memory for the integrator's copy of the optical-depth table (%zu bytes), on the device or pinned on the host", cbytes);
+            }
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostFree(h); return fail(VP_E_NOMEM, "pinned host memory is not visible to the device"); }
+            G.d_opacity_cells = (float*)d; G.h_opacity_cells = h;
+            if (G.use_opacity_cells)   // (not when the knob asked for it)
+                fprintf(stderr, "volpath_hip: no device memory for the integrator's copy of the optical-depth table (%zu MB): it lies in pinned host "
+                                "memory, frames from 11 on are read across the bus (same results, slow)\n", cbytes >> 20);
+        }
     }
+    launch_pack_f32(G.d_opacity, G.d_opacity_cells, G.S.nx, G.S.ny, G.S.nz, false, G.stream);
+    HIPCHK(hipGetLastError());
     G.S.opacity = G.d_opacity;
     G.S.opacity_cells = G.d_opacity_cells;
     return VP_OK;
