@@ -805,3 +805,81 @@ def test_full_size_workloads_match_the_oracle_on_sampled_pixels(vp, oracle, work
     assert bad == 0, f"{bad} of {len(pick)} sampled pixels differ"
     assert (got[..., 3] > 0).mean() > 0.05
     vp.set_camera()
+
+
+def test_ragged_grid_beyond_512_matches_the_oracle_on_sampled_pixels_and_voxels(vp, oracle):
+    """"nothing tests a non-cubic or > 512^3 grid against [the packed optical-depth cells]".  A soft 640 x 352 x 416 volume
+    (x beyond 512, every edge different, none a multiple of the 16-voxel brick on y) in the box the reference derives from the
+    dimensions (kernel.cu:373-378), chromatic preset, the live estimator with 16^3 bricks, frames 9..12 -- across the switch to the
+    optical-depth table -- on the bench's streams: (1) the table opacity_lds_k builds (8x8x8 blocks of a grid whose y and z edges are
+    not multiples of 8 or of the tile) against the oracle's march on 2048 + 56 voxels, tolerance 0; (2) the image against the oracle
+    on up to 700 sampled pixels, tolerance 0, the integrator reading that table from its packed cells (3 GB here)."""
+    import ctypes as C
+    from scipy import ndimage
+    nx, ny, nz = 640, 352, 416
+    rs = np.random.default_rng(77)
+    low = rs.random((nz // 16, ny // 16, nx // 16)).astype(np.float32)
+    g = ndimage.zoom(low, 16, order=1)                      # soft: trilinear upsampling of a coarse random field
+    g = np.clip((g - 0.45) * 3.0, 0.0, 1.0)
+    grid = np.ascontiguousarray((g * 255).astype(np.uint8))
+    assert grid.shape == (nz, ny, nx) and 0.2 < (grid > 0).mean() < 0.8
+    env = scenes.synthetic_env()
+    W, H, first, frames = 160, 96, 9, 4
+    vp.init_volume(grid, brick=16, linear=True)
+    vp.init_envmap(env)
+    vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+    vp.set_camera()
+    vp.set_estimator(vp.EST_DECOMP)
+    vp.set_tracking(0)
+    vp.set_rng(vp.RNG_PHILOX7, (5, 6))
+    vp.set_shard(0, 1)
+    vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+    P = vp.make_param(W, H, density=120.0)
+    vp.mat(P, *scenes.PRESET1)
+    buf = vp.DeviceBuffer(W, H)
+    vp.render_frames(buf.ptr, first, frames, P)
+    got = buf.download()
+    buf.free()
+    osc = oracle.OracleScene(grid, env, scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER, brick=16, estimator=oracle.EST_DECOMP,
+                             rng_mode=oracle.RNG_PHILOX7, seed=(5, 6))
+    # (1) the table
+    table = vp.opacity_table((nz, ny, nx))
+    ijk = [np.stack([rs.integers(0, nx, 2048), rs.integers(0, ny, 2048), rs.integers(0, nz, 2048)], 1)]
+    ijk.append(np.array([[a, b, c] for a in (0, nx - 1) for b in (0, ny - 1) for c in (0, nz - 1)]))
+    for axis, n in enumerate((nx, ny, nz)):
+        for side in (0, n - 1):
+            f = np.stack([rs.integers(0, nx, 8), rs.integers(0, ny, 8), rs.integers(0, nz, 8)], 1)
+            f[:, axis] = side
+            ijk.append(f)
+    ijk = np.concatenate(ijk).astype(np.int32)
+    want = osc.opacity_voxels(ijk)
+    tgot = table[ijk[:, 2], ijk[:, 1], ijk[:, 0]]
+    bad = np.nonzero(tgot != want)[0]
+    assert len(bad) == 0, f"{len(bad)} of {len(ijk)} voxels differ: first {ijk[bad[0]]} {tgot[bad[0]]} vs {want[bad[0]]}"
+    assert (want > 0).mean() > 0.5
+    # (2) the image, the oracle reading the table just checked
+    osc.opacity = table
+    osc.S.opacity = osc.opacity.ctypes.data
+    oP = oracle.default_param(W, H, density=120.0)
+    oracle.mat(oP, *scenes.PRESET1)
+    ys, xs = np.nonzero(got[..., 3] > 0)
+    sel = rs.choice(len(ys), min(600, len(ys)), replace=False)
+    pick = list(zip(ys[sel], xs[sel]))
+    ys0, xs0 = np.nonzero(got[..., 3] == 0)
+    if len(ys0):
+        sel0 = rs.choice(len(ys0), min(100, len(ys0)), replace=False)
+        pick += list(zip(ys0[sel0], xs0[sel0]))
+    L = oracle.lib()
+    out = (C.c_float * 4)()
+    cnt = oracle.Counters()
+    wrong = 0
+    for y, x in pick:
+        acc = np.zeros(4, np.float32)
+        for f in range(first, first + frames):
+            L.vpo_render_sample(C.byref(osc.S), C.byref(oP), int(x), int(y), f, out, C.byref(cnt))
+            acc = acc + np.array(out[:], np.float32)
+        if not np.array_equal(acc, got[y, x]):
+            wrong += 1
+    assert wrong == 0, f"{wrong} of {len(pick)} sampled pixels differ"
+    assert cnt.opacity_lookups > 1000 and (got[..., 3] > 0).mean() > 0.2        # deep paths read the table; the volume is in view
+    vp.set_camera()
