@@ -370,6 +370,7 @@ void render_k(SceneDev S, LaunchDev L)
     // ... and, for the three blocks a regrouping of work would have to fill (collision, end of flight, restart set-up), the HISTOGRAM of
     // lanes per execution in eight buckets of eight lanes (round 5: profiles/experiments/r05_wavefront_break_even.md)
     unsigned long long hist[3][8] = {};
+    unsigned long long ctrl_w = 0, ctrl_l = 0;
     auto tally = [&](int b, bool on) __attribute__((always_inline)) {
         if (PROF)
         {
@@ -1003,6 +1004,12 @@ ends_done:
                     // phase_g and cur_density of this scatter count: segment_medium().  Scalar build: no local bound (:2063 / :1745)
                     sigma_t_prime = TRK ? cur_density : max_sig * cur_density * d_max;
                     inv_sigma_t   = 1.0f / sigma_t_prime;
+                    if (PROF)
+                    {
+                        // (how often the control component's 65 instructions -- a draw, a logarithm, two divisions -- run, and for how many lanes)
+                        const unsigned long long cm = __ballot(TRK == 0 && EST == EST_DECOMP && d_min > 0.0f);
+                        if (cm) { ctrl_w += 1; ctrl_l += (unsigned)__popcll(cm); }
+                    }
                     if (TRK == 0 && EST == EST_DECOMP && d_min > 0.0f)
                     {
                         // analog decomposition tracking kernel.cu:2048-2054 (quirk Q7)
@@ -1330,6 +1337,7 @@ ends_done:
             for (int h = 0; h < 3; h++)
 #pragma unroll
                 for (int q = 0; q < 8; q++) atomicAdd(&L.counters[48 + 8 * h + q], hist[h][q]);
+            atomicAdd(&L.counters[72], ctrl_w); atomicAdd(&L.counters[73], ctrl_l);
         }
     }
 }

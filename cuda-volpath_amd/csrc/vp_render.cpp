@@ -422,6 +422,7 @@ int vp_read_counters(vp_counters* out, int reset)
             fprintf(stderr, "[vp] block: wave executions, lanes per execution (of 64)\n");
             for (int b = 0; b < 15; b++)
                 if (h[16 + 2 * b]) fprintf(stderr, "[vp]   %-18s %14llu  %5.1f\n", names[b], h[16 + 2 * b], (double)h[17 + 2 * b] / (double)h[16 + 2 * b]);
+            if (h[72]) fprintf(stderr, "[vp]   %-18s %14llu  %5.1f\n", "control component", h[72], (double)h[73] / (double)h[72]);
             static const char* hn[3] = {"scatter", "segment/ray end", "setup"};
             for (int q = 0; q < 3; q++)
             {

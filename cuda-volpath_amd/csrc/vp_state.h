@@ -209,7 +209,7 @@ State& cur();
 constexpr size_t kMaxPendingEvents = 64;
 
 constexpr size_t kQueueWords = VP_NQUEUES * VP_QUEUE_STRIDE;  // queue heads of one launch
-constexpr size_t kCounterWords = 72;  // 6 work counters, 6 loop statistics, 15 x (wave, lane) block tallies from word 16, 3 x 8 histogram buckets from word 48
+constexpr size_t kCounterWords = 74;  // 6 work counters, 6 loop statistics, 15 x (wave, lane) block tallies from word 16, 3 x 8 histogram buckets from word 48, the control-component tally at 72
 
 int fail(int code, const char* fmt, ...);
 [[noreturn]] void die(const char* what);
