@@ -246,6 +246,18 @@ __global__ void light_identity_k(ParamDev P, int local, const unsigned* mask, un
                                // spill four or five at six waves and run as the LDS-table kernel's helper workgroups, where a fifth wave is
                                // all a SIMD has room for: they keep five
 #endif
+// Waves per SIMD the register budget of a render_k instance is held to (the second argument of its __launch_bounds__), one case per
+// line instead of the nested conditional it used to be; the reasons are in the comment at the kernel:
+constexpr int render_min_waves(int est, bool count, int ldsb, bool ach, bool mis, int trk, bool light, bool cancel)
+{
+    if (VP_MIN_WAVES > 1) return VP_MIN_WAVES;                                            // a build-wide override
+    if (light) return count ? 5 : (est != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES);
+    if (mis || ldsb == 1) return 1;                                                        // the MIS build; the 16-bit LDS table (512-thread workgroups)
+    if (count) return 4;                                                                   // counting variants: untimed, no spills
+    if (est == EST_GLOBAL && trk == 0) return VP_GLOBAL_MIN_WAVES;
+    if (trk) return 4;                                                                     // scalar tracking builds
+    return (ach && !cancel) ? VP_LOCAL_MIN_WAVES : 5;                                      // local majorants: achromatic six, chromatic / look-ahead five
+}
 template <int EST, class RNG, bool QUANT, bool COUNT, int LDSB, bool ACH, bool MIS, int TRK, bool LIGHT = false, bool CANCEL = false>
 // Occupancy (round 4: the cold per-path state in LDS, ColdVal above; profiles/r04_kernel_resources.txt).  The achromatic
 // global-majorant kernel needs 72 registers: SEVEN waves per SIMD (C2 2541 -> 2781 Msamples/s); the chromatic one and the plain
@@ -254,8 +266,7 @@ template <int EST, class RNG, bool QUANT, bool COUNT, int LDSB, bool ACH, bool M
 // three spilled registers and lost).
 // (CANCEL instances of the local-majorant kernels: look-ahead batches are launched with five workgroups per CU -- vp_render.cpp -- so five
 // waves are what their registers are budgeted for: no spill.)
-__global__ __launch_bounds__(LDSB == 1 ? VP_BLOCK_LDS : VP_BLOCK,
-                             (VP_MIN_WAVES > 1) ? VP_MIN_WAVES : (LIGHT ? (COUNT ? 5 : (EST != EST_GLOBAL ? VP_LIGHT_LOCAL_MIN_WAVES : VP_LIGHT_MIN_WAVES)) : MIS || LDSB == 1 ? 1 : COUNT ? 4 : (EST == EST_GLOBAL && TRK == 0 ? VP_GLOBAL_MIN_WAVES : (TRK ? 4 : (ACH && !CANCEL ? VP_LOCAL_MIN_WAVES : 5)))))
+__global__ __launch_bounds__(LDSB == 1 ? VP_BLOCK_LDS : VP_BLOCK, render_min_waves(EST, COUNT, LDSB, ACH, MIS, TRK, LIGHT, CANCEL))
 void render_k(SceneDev S, LaunchDev L)
 {
     __shared__ unsigned short lds_bounds[LDSB == 1 ? VP_LDS_BOUND_ENTRIES : 1];
