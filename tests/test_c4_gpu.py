@@ -883,3 +883,99 @@ def test_ragged_grid_beyond_512_matches_the_oracle_on_sampled_pixels_and_voxels(
     assert wrong == 0, f"{wrong} of {len(pick)} sampled pixels differ"
     assert cnt.opacity_lookups > 1000 and (got[..., 3] > 0).mean() > 0.2        # deep paths read the table; the volume is in view
     vp.set_camera()
+
+
+def test_lookahead_habit_decays_when_nobody_reads_the_speculative_batches(vp):
+    """once a caller had been served a staged frame, EVERY first frame of a run had a speculative 32-frame batch queued
+    beside it -- an interactive drag (each call is frame 0 of a new camera) paid for a batch per move that the next move threw away.
+    Now a speculative batch that goes unserved clears the habit until a staged frame is served again: a drag of twelve moves after a
+    converged run launches ONE more batch, not twelve; the images stay the explicit launches' (the look-ahead is invisible)."""
+    from volpath import scene as vscene, host
+    P, info = vscene.setup("c1", rng_mode=vp.RNG_PHILOX7, last_frame=80)
+    W, H = P.width, P.height
+    vp.set_lookahead(vp.LOOKAHEAD_DEFAULT)
+    a, ref = vp.DeviceBuffer(W, H), vp.DeviceBuffer(W, H)
+    try:
+        for f in range(40):                              # a converging run: the ramp starts, staged frames are served -> the habit is on
+            vp.render_kernel(a.ptr, f, P)
+            vp.synchronize()
+        l0, _ = vp.lookahead_stats()
+        cams = [tuple(float(v) for v in host.camera_matrix((3.9 * np.cos(t), -0.78, 3.9 * np.sin(t)), (-np.cos(t), 0.2, -np.sin(t)), (0.0, 1.0, 0.0)))
+                for t in np.linspace(0.1, 1.2, 12)]
+        for cam in cams:                                 # the drag: one frame per camera
+            vp.set_camera(cam)
+            a.reset()
+            vp.render_kernel(a.ptr, 0, P)
+            vp.synchronize()
+        l1, _ = vp.lookahead_stats()
+        assert l1 - l0 <= 2, f"{l1 - l0} batches launched during a drag of {len(cams)} moves"
+        got = a.download()
+        vp.set_lookahead(0)
+        ref.reset()
+        vp.render_frames(ref.ptr, 0, 1, P)
+        assert np.array_equal(got, ref.download())
+        # ... and the habit comes back with the next converging run
+        vp.set_lookahead(vp.LOOKAHEAD_DEFAULT)
+        a.reset()
+        for f in range(40):
+            vp.render_kernel(a.ptr, f, P)
+            vp.synchronize()
+        l2, _ = vp.lookahead_stats()
+        assert l2 - l1 >= 1
+        ref.reset()
+        vp.set_lookahead(0)
+        vp.render_frames(ref.ptr, 0, 40, P)
+        assert np.array_equal(a.download(), ref.download())
+    finally:
+        vp.set_lookahead(vp.LOOKAHEAD_DEFAULT)
+        vp.set_camera()
+        a.free(); ref.free()
+
+
+def test_exit_flights_switched_on_after_the_volume_build_their_table(vp, oracle):
+    """vp_set_exit_flights(1 / 2) after a volume was initialised with exit flights off did nothing, and vp_get_exit_table
+    then failed.  A context created under VP_NO_EXIT=1 initialises its volume without the table; switching the mode on builds it, the
+    table equals the one a default context builds, and the image is the same bits either way."""
+    grid = oracle.julia(48)
+    env = scenes.synthetic_env()
+    W, H = 64, 48
+
+    def scene():
+        vp.init_volume(grid, brick=1, linear=True)
+        vp.init_envmap(env)
+        vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER)
+        vp.set_camera()
+        vp.set_estimator(vp.EST_GLOBAL)
+        vp.set_tracking(0)
+        vp.set_rng(vp.RNG_PHILOX7, (9, 9))
+        vp.set_shard(0, 1)
+
+    def render():
+        P = vp.make_param(W, H)
+        buf = vp.DeviceBuffer(W, H)
+        vp.render_frames(buf.ptr, 0, 6, P)
+        out = buf.download()
+        buf.free()
+        return out
+
+    scene()
+    want_img, want_tab = render(), vp.exit_table((48, 48, 48))
+    saved = os.environ.get("VP_NO_EXIT")
+    os.environ["VP_NO_EXIT"] = "1"
+    ctx = vp.Context(0)
+    try:
+        with ctx:
+            scene()
+            with pytest.raises(vp.VolpathError):
+                vp.exit_table((48, 48, 48))              # off: no table
+            off_img = render()
+            vp.set_exit_flights(1)                       # on, after the volume: the table is built now
+            assert np.array_equal(vp.exit_table((48, 48, 48)), want_tab)
+            on_img = render()
+    finally:
+        ctx.destroy()
+        if saved is None:
+            del os.environ["VP_NO_EXIT"]
+        else:
+            os.environ["VP_NO_EXIT"] = saved
+    assert np.array_equal(off_img, want_img) and np.array_equal(on_img, want_img)
