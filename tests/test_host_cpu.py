@@ -201,6 +201,11 @@ def test_bench_final_line_stays_under_three_kilobytes():
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
         assert r["kernel"] == "vp::render_k" and len(r["bounded_by"]) <= 40 and r["traffic"] > 0 and r["launch_ms"] > 0
         assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] == "port"
+        # the line is self-consistent after the rounding: value = samples per step / time per step; the launches fit the steps
+        assert abs(line["value"] - line["config"]["samples_per_step"] / (line["ms_per_step"] * 1e-3) / 1e6) < 2e-4 * line["value"]
+        assert r["launches"] * r["launch_ms"] <= line["steps"] * line["ms_per_step"] * 1.0001
+        for w in line["secondary"].values():
+            assert w["general"] is None or w["general"] > 0
         assert set(line["secondary"]) == {"c3", "c3ref_samplerh", "c4s", "c4f"}
         for w in line["secondary"].values():
             assert set(w) == {"value", "general", "ms_per_step", "steps", "spp", "frac", "traffic_ratio", "lane_util", "cpu"} and w["value"] > 0
