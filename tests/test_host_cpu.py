@@ -155,7 +155,8 @@ def test_dense_dump_roundtrip_and_quantisers(host, tmp_path):
 def test_bench_cpu_baseline_leg_runs_for_every_estimator(host):
     """bench.py's cpu_baseline (the oracle timed on the host) must work for the decomposition workloads too.  At 128^3 the
     optical-depth volume is affordable on the CPU, so the sample runs across the frame-11 switch of the live kernel (quirk
-    Q5); at 256^3 and above it stays within frames 0..10 and says so."""
+    Q5); at 256^3 and above bench.py hands it the table the GPU leg built (the oracle's own, bit for bit: tests/test_c4_gpu.py) and the
+    sample runs frames 10.., across the switch; without a table it stays within frames 0..10 and says so."""
     import importlib.util
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
