@@ -211,6 +211,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         const bool ach_lds = p->sigma_t.x == p->sigma_t.y && p->sigma_t.y == p->sigma_t.z && p->albedo.x == p->albedo.y && p->albedo.y == p->albedo.z;
         const int lds_form = !lds_bounds ? 0 : (G.bound_codes_ok && G.d_bound_codes && !G.count && !tgt && G.rng != VP_RNG_SAMPLERH &&
                                                 (ach_lds || G.lds_compact_chromatic)) ? 2 : 1;
+        G.last_lds_form = lds_form;
         L.bound_codes = lds_form == 2 ? G.d_bound_codes : nullptr;
         L.bound_pal[0] = G.bound_pal[0]; L.bound_pal[1] = G.bound_pal[1];
         hipEvent_t e0 = get_event(), e1 = get_event();
@@ -463,6 +464,7 @@ int vp_render_time_ms(double* total_ms, int* launches, int reset)
 }
 int vp_last_approach_mode(void) { return G.last_approach; }
 int vp_last_light_const(void) { return G.last_light_const; }
+int vp_last_lds_form(void) { return G.last_lds_form; }
 int vp_lookahead_stats(unsigned* launched, unsigned* cancelled_in_flight)
 {
     if (launched) *launched = G.la_launched;

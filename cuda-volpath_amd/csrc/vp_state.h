@@ -160,6 +160,7 @@ struct State
     size_t      appr_aux_bytes[3] = {0, 0, 0};
     int         last_approach = 0;            // vp_last_approach_mode
     int         last_light_const = 0;         // vp_last_light_const
+    int         last_lds_form = 0;            // vp_last_lds_form
     unsigned    la_launched = 0, la_cancelled = 0;   // vp_lookahead_stats
     bool        use_const_rows = true;        // VP_NO_CONST_ROWS=1: per-pixel constants are staged for every frame, as before round 4's end
     unsigned    last_const_from = 0;          // LaunchDev::const_from of the last staged launch (a look-ahead slot keeps it for its add-kernels)

@@ -214,6 +214,11 @@ int vp_last_approach_mode(void);
 /* 1 if the last render call of this context wrote its light class (pixels whose camera ray meets empty cells only) as per-pixel
  * constants (miss_fill_k: a null collision in empty space leaves a throughput of 1 as it is in this medium), 0 if it integrated it. */
 int vp_last_light_const(void);
+/* How the last render launch of the decomposition estimator read its brick table: 0 from global memory, 1 as 16-bit (max,min) pairs
+ * staged through LDS, 2 as 2-bit codes into a four-entry palette staged through LDS beside the cold per-path state (tables with at
+ * most four distinct pairs -- binary volumes --, achromatic media, timed launches of the counter-based streams).  Performance
+ * only: the three forms render the same bits (VP_NO_LDS_BOUNDS / VP_NO_LDS_COMPACT select them). */
+int vp_last_lds_form(void);
 /* test hook: look-ahead batches this context has launched so far (render_kernel's staged frames), and how many of them were told to
  * stop while they were still running (a setter, a camera move); either pointer may be NULL */
 int vp_lookahead_stats(unsigned* launched, unsigned* cancelled_in_flight);

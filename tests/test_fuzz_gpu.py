@@ -174,6 +174,92 @@ def test_random_scene_bit_exact(vp, oracle, seed):
         buf.free()
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VP_FUZZ_BINARY", "16"))))
+def test_random_binary_volume_takes_the_compact_lds_table(vp, oracle, seed):
+    """Round 5: a brick table with at most four distinct (max,min) pairs goes through LDS as 2-bit codes beside the cold per-path state
+    (render_k<..., LDSB = 2>) -- for achromatic media, timed launches, counter-based streams; chromatic media, counting launches, the
+    sampler.h stream and frame-by-frame render_kernel calls keep the 16-bit table or global memory.  The randomised scenes above are
+    soft volumes (hundreds of pairs) and never take that form: these are BINARY volumes {0, v} of random ragged shapes, random boxes,
+    cameras, media, brick sizes and first frames (half of them across the frame-11 switch), decomposition estimator.  The timed
+    launch, the counting launch and the frame-by-frame path must all equal the oracle bit for bit; vp_last_lds_form says which form
+    the timed launch took."""
+    from volpath import host
+    rng = np.random.default_rng(5000 + seed)
+    nz, ny, nx = (int(rng.integers(9, 41)) for _ in range(3))
+    z, y, x = np.mgrid[0:nz, 0:ny, 0:nx].astype(np.float32)
+    g = np.zeros((nz, ny, nx), bool)
+    for _ in range(int(rng.integers(1, 6))):                         # a few ellipsoids
+        c = rng.uniform(0.2, 0.8, 3) * (nx, ny, nz)
+        r = rng.uniform(0.08, 0.35, 3) * (nx, ny, nz)
+        g |= ((x - c[0]) / r[0]) ** 2 + ((y - c[1]) / r[1]) ** 2 + ((z - c[2]) / r[2]) ** 2 < 1.0
+    level = int(rng.choice([255, 255, 200, 37]))
+    grid = np.ascontiguousarray(g.astype(np.uint8) * np.uint8(level))
+    if rng.random() < 0.5:
+        box, bmin, bmax = None, np.array([-1.0, -ny / nx, -nz / nx]), np.array([1.0, ny / nx, nz / nx])
+    else:
+        bmin = rng.uniform(-2.0, 0.5, 3)
+        bmax = bmin + rng.uniform(0.5, 3.0, 3)
+        box = (tuple(float(np.float32(v)) for v in bmin), tuple(float(np.float32(v)) for v in bmax))
+    brick = int(rng.choice([2, 4, 8]))
+    rng_mode = int(rng.choice([1, 2, 2, 0]))
+    chromatic = bool(rng.random() < 0.3)
+    W, H = int(rng.integers(8, 57)), int(rng.integers(8, 41))
+    thickness = 10.0 ** rng.uniform(0.5, 2.5)
+    kw = dict(density=float(np.float32(thickness / (float(np.linalg.norm(bmax - bmin)) * level / 255.0))), g=float(np.float32(rng.uniform(-0.5, 0.95))))
+    if chromatic:
+        kw["sigma_t"] = tuple(float(np.float32(v)) for v in rng.uniform(0.2, 1.0, 3))
+        kw["albedo"] = tuple(float(np.float32(v)) for v in rng.uniform(0.3, 1.0, 3))
+    sun = rng.normal(size=3)
+    sun /= np.linalg.norm(sun)
+    sun_dir = tuple(float(np.float32(v)) for v in sun)
+    sun_power = tuple(float(np.float32(v)) for v in rng.uniform(0.0, 5.0e4, 3))
+    env = scenes.synthetic_env(w=int(rng.integers(1, 40)), h=int(rng.integers(1, 20)), seed=seed)
+    cam = _random_camera(rng, host, (bmin + bmax) / 2, (bmax - bmin) / 2)
+    key = (int(rng.integers(0, 2 ** 31)), int(rng.integers(0, 2 ** 31)))
+    late = bool(rng.random() < 0.5) and nx * ny * nz <= 24 ** 3
+    first, nframes = (9, 4) if late else (int(rng.choice([0, 3])), int(rng.integers(2, 5)))
+    c = dict(grid=grid, box=box, est=1, rng_mode=rng_mode, linear=True, brick=brick, W=W, H=H, kw=kw, sun_dir=sun_dir, sun_power=sun_power,
+             env=env, cam=cam, key=key, late=late, first=first, nframes=nframes, env_mis=False, track=0, world=1)
+    ref, cnt = _oracle_render(oracle, c)
+    what = dict(seed=seed, grid=grid.shape, level=level, box=box, rng=rng_mode, brick=brick, size=(W, H), first=first, nframes=nframes, chromatic=chromatic, **kw)
+    vP = vp.make_param(W, H, **kw)
+    buf = vp.DeviceBuffer(W, H)
+    try:
+        vp.init_volume(grid, box=box, brick=brick, linear=True)
+        vp.init_envmap(env)
+        vp.set_sun(sun_dir, sun_power)
+        vp.set_camera(cam)
+        vp.set_estimator(1)
+        vp.set_rng(rng_mode, key)
+        vp.set_tracking(0)
+        vp.set_envmap_sampling(vp.ENV_PASSIVE)
+        vp.set_shard(0, 1)
+        if late:
+            vp.precompute_opacity(sun_dir)
+        vp.render_frames(buf.ptr, first, nframes, vP)               # the timed launch
+        got = buf.download()
+        form = vp.last_lds_form()
+        assert np.array_equal(got, ref, equal_nan=True), (what, form, float(np.nanmax(np.abs(got - ref))))
+        assert form == (2 if (not chromatic and rng_mode != 0) else 1), (what, form)
+        vp.enable_counters(True)                                     # the counting launch: the 16-bit table, the estimator's counters
+        vp.read_counters(reset=True)
+        buf.reset()
+        vp.render_frames(buf.ptr, first, nframes, vP)
+        k = vp.read_counters()
+        vp.enable_counters(False)
+        assert vp.last_lds_form() == 1 and np.array_equal(buf.download(), ref, equal_nan=True), what
+        for q in ("samples", "density_lookups", "bound_lookups", "opacity_lookups", "env_lookups", "scatters"):
+            assert k[q] == cnt[q], (what, q, k[q], cnt[q])
+        buf.reset()
+        for f in range(first, first + nframes):                     # frame by frame through the reference's entry point
+            vp.render_kernel(buf.ptr, f, vP)
+        assert np.array_equal(buf.download(), ref, equal_nan=True), what
+    finally:
+        vp.enable_counters(False)
+        vp.set_camera()
+        buf.free()
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VP_FUZZ_SEQUENCES", "8"))))
 def test_random_call_sequences(vp, oracle, seed):
     _run_call_sequence(vp, oracle, seed, extra=False)
