@@ -91,6 +91,7 @@ int ensure_device()
     if (knob("VP_NO_CRAWL_TABLE", 0, 1, v)) G.use_crawl_table = v == 0;
     if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;
     if (knob("VP_NO_SUN_CLIP", 0, 1, v)) G.use_sun_clip = v == 0;
+    if (knob("VP_DENSE_PERCENT", 0, 101, v)) G.dense_fraction = (float)v / 100.0f;
     if (knob("VP_NO_OPACITY_LDS", 0, 1, v)) G.opacity_lds = v == 0;
     if (knob("VP_NO_OPACITY_CELLS", 0, 1, v)) G.use_opacity_cells = v == 0;
     if (knob("VP_NO_LIGHT_CONST", 0, 1, v)) G.use_light_const = v == 0;
@@ -297,10 +298,18 @@ int do_init_volume_(const void* h_volume, vp_extent ext, bool quantized, const v
     // cells with a non-empty cell in their neighbourhood: input of the certified-empty table of the global-majorant estimator
     if (G.use_empty_table && hipMalloc((void**)&G.d_danger, n) == hipSuccess)
     {
-        launch_danger(S, quantized, G.d_danger, G.stream);
+        // (the counter: the last word of the work-counter block is nobody's)
+        unsigned long long* d_marked = G.d_counters + (kCounterWords - 1);
+        HIPCHK(hipMemsetAsync(d_marked, 0, sizeof(unsigned long long), G.stream));
+        launch_danger(S, quantized, G.d_danger, d_marked, G.stream);
         HIPCHK(hipGetLastError());
+        unsigned long long marked = 0;
+        HIPCHK(hipMemcpyAsync(&marked, d_marked, sizeof marked, hipMemcpyDeviceToHost, G.stream));
+        HIPCHK(hipStreamSynchronize(G.stream));
+        HIPCHK(hipMemsetAsync(d_marked, 0, sizeof(unsigned long long), G.stream));
+        G.marked_fraction = (float)((double)marked / (double)n);
     }
-    else { (void)hipGetLastError(); G.d_danger = nullptr; }  // no memory for it: the estimator fetches every cell, same bits
+    else { (void)hipGetLastError(); G.d_danger = nullptr; G.marked_fraction = 0.0f; }  // no memory for it: the estimator fetches every cell, same bits
     // ... and of the direction table of the exit flights
     if (G.d_danger && G.use_exit && hipMalloc((void**)&G.d_exit, 3 * n) == hipSuccess)
     {

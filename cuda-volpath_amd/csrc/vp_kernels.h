@@ -166,7 +166,8 @@ void launch_env_tables(const float4* env, int w, int h, float* lum, float* row_s
                        hipStream_t st);
 void launch_crawl_table(const SceneDev& S, bool quant, unsigned width, unsigned height, bool control_draw, const unsigned char* danger, float4* table,
                         hipStream_t st);
-void launch_danger(const SceneDev& S, bool quant, unsigned char* out, hipStream_t st);
+// marked (may be null): a device counter that receives the number of cells marked (a non-empty cell in the 3x3x3 neighbourhood)
+void launch_danger(const SceneDev& S, bool quant, unsigned char* out, unsigned long long* marked, hipStream_t st);
 float sun_clip_step(const SceneDev& S);  // the table's distance unit: a quarter of the smallest cell edge
 void launch_sun_clip(const SceneDev& S, const unsigned char* danger, float ds, unsigned short* out, hipStream_t st);
 void launch_empty_table(const SceneDev& S, unsigned width, unsigned height, const unsigned char* danger, float4* table, hipStream_t st);

@@ -1409,7 +1409,7 @@ __global__ __launch_bounds__(256) void crawl_table_k(SceneDev S, unsigned width,
 // march and the integrator compute.  The integrator's free-flight steps before that distance skip the fetch and use the +0
 // it would have produced (render_k, tracking_step): same bits, ~65 fewer instructions and no memory access per step.
 template <bool QUANT>
-__global__ __launch_bounds__(256) void danger_k(SceneDev S, unsigned char* out)
+__global__ __launch_bounds__(256) void danger_k(SceneDev S, unsigned char* out, unsigned long long* marked)
 {
     size_t n   = (size_t)S.nx * S.ny * S.nz;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1443,6 +1443,12 @@ __global__ __launch_bounds__(256) void danger_k(SceneDev S, unsigned char* out)
         }
     }
     out[idx] = (unsigned char)((any ? 1 : 0) | (self ? 2 : 0));
+    // how much of the grid is marked (round 5): the host switches the tables that pay in EMPTY space off for volumes that have little
+    if (marked)
+    {
+        const unsigned long long m = __ballot(any);
+        if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m | (1ull << 63)) && m) atomicAdd(marked, (unsigned long long)__popcll(m));
+    }
 }
 // ---- the direction table of the exit flights (render_k).  Three byte planes, one per DOMINANT axis A of a direction in cell
 // units (|e_A| >= |e_B|, |e_C| with e = d * N / extent; (B, C) = the other two axes in increasing order); in plane A bit
@@ -2668,12 +2674,12 @@ void launch_crawl_table(const SceneDev& S, bool quant, unsigned width, unsigned 
     if (quant) hipLaunchKernelGGL(crawl_table_k<true>, dim3((n + 255) / 256), dim3(256), 0, st, S, width, height, control_draw ? 1 : 0, danger, table);
     else hipLaunchKernelGGL(crawl_table_k<false>, dim3((n + 255) / 256), dim3(256), 0, st, S, width, height, control_draw ? 1 : 0, danger, table);
 }
-void launch_danger(const SceneDev& S, bool quant, unsigned char* out, hipStream_t st)
+void launch_danger(const SceneDev& S, bool quant, unsigned char* out, unsigned long long* marked, hipStream_t st)
 {
     size_t n = (size_t)S.nx * S.ny * S.nz;
     dim3   g((unsigned)((n + 255) / 256));
-    if (quant) hipLaunchKernelGGL(danger_k<true>, g, dim3(256), 0, st, S, out);
-    else hipLaunchKernelGGL(danger_k<false>, g, dim3(256), 0, st, S, out);
+    if (quant) hipLaunchKernelGGL(danger_k<true>, g, dim3(256), 0, st, S, out, marked);
+    else hipLaunchKernelGGL(danger_k<false>, g, dim3(256), 0, st, S, out, marked);
 }
 void launch_exit_table(const unsigned char* danger, unsigned char* planes, int nx, int ny, int nz, hipStream_t st)
 {

@@ -111,7 +111,8 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     // the camera rays' free flights through certified-empty cells in kernels of their own, ahead of the integrator (approach_k: global
     // majorant; approach_local_k: decomposition estimator; spectral tracking, passive environment, staged launches)
     bool approach = false, approach_thr = false;
-    if (G.use_approach && (G.est == VP_EST_GLOBAL || (G.est == VP_EST_DECOMP && G.use_approach_local)) && !G.trk && !G.env_mis && L.crawl && G.n_general &&
+    const bool dense_volume = G.marked_fraction > G.dense_fraction;   // (vp_state.h: little empty space for the walk to cross)
+    if (G.use_approach && (G.est == VP_EST_GLOBAL || (G.est == VP_EST_DECOMP && G.use_approach_local && !dense_volume)) && !G.trk && !G.env_mis && L.crawl && G.n_general &&
         (!G.count || getenv("VP_COUNT_APPROACH")))   // counting launches: the integrator makes every step itself unless asked (block tallies)
     {
         // global majorant: one majorant for the whole walk, checked here; decomposition: approach_local_k checks each segment's own
@@ -556,7 +557,7 @@ int vp_reserve_frames(const Param* p, int nframes)
     const size_t f    = std::min<size_t>((size_t)nframes, stage_frames_cap(sh.per_frame, G.stage_bytes));
     const size_t need = sh.per_frame * f * sizeof(float4);
     // (decomposition estimator: the stream's state beside each staging slot of the approach kernel's hand-over, do_render)
-    const size_t need4 = (G.est == VP_EST_DECOMP && G.use_approach && G.use_approach_local) ? sh.per_frame * f * sizeof(uint2) : 0;
+    const size_t need4 = (G.est == VP_EST_DECOMP && G.use_approach && G.use_approach_local && !(G.marked_fraction > G.dense_fraction)) ? sh.per_frame * f * sizeof(uint2) : 0;
     if (need4 > G.appr_aux_bytes[0])
     {
         HIPCHK(hipStreamSynchronize(G.stream));

@@ -149,6 +149,12 @@ struct State
     std::vector<unsigned char> crawl_key;
     // counter-based streams: where a sun shadow ray has only empty cells left (sun_clip_k), per cell; rebuilt when the volume, the
     // box or the sun direction changes
+    // Tables that pay in EMPTY space -- the sun table (a shadow ray ends where only empty cells are left) and the decomposition
+    // estimator's approach walk -- are switched off for volumes with little of it: where more than dense_fraction of the cells have a
+    // non-empty cell in their 3x3x3 neighbourhood (danger_k counts them).  Measured (profiles/experiments/r05_dense_volumes.txt): the
+    // Julia sets (7 % marked) gain 15-27 % from the sun table, the frame-filling cloud (54 %) LOSES 1 % to each of the two.  Results
+    // never depend on it.  VP_DENSE_PERCENT overrides the threshold (101: never dense).
+    float       marked_fraction = 0.0f, dense_fraction = 0.40f;
     bool        use_sun_clip = true;
     unsigned short* d_sunclip = nullptr;
     float       sunclip_ds  = 0.0f;
@@ -210,7 +216,7 @@ State& cur();
 constexpr size_t kMaxPendingEvents = 64;
 
 constexpr size_t kQueueWords = VP_NQUEUES * VP_QUEUE_STRIDE;  // queue heads of one launch
-constexpr size_t kCounterWords = 74;  // 6 work counters, 6 loop statistics, 15 x (wave, lane) block tallies from word 16, 3 x 8 histogram buckets from word 48, the control-component tally at 72
+constexpr size_t kCounterWords = 76;  // 6 work counters, 6 loop statistics, 15 x (wave, lane) block tallies from word 16, 3 x 8 histogram buckets from word 48, the control-component tally at 72, danger_k's marked-cell count in the last word
 
 int fail(int code, const char* fmt, ...);
 [[noreturn]] void die(const char* what);

@@ -158,6 +158,7 @@ int ensure_sun_clip(const unsigned short** out, float* ds)
 {
     *out = nullptr; *ds = 0.0f;
     if (!G.use_sun_clip || G.rng == VP_RNG_SAMPLERH || !G.d_danger || !G.linear) return VP_OK;
+    if (G.marked_fraction > G.dense_fraction) return VP_OK;   // a dense volume: the table costs a lookup per collision and ends few rays early (vp_state.h)
     struct K { int nx, ny, nz, quant; float bmin[3], bmax[3], sun[3]; unsigned long long epoch; };
     std::vector<unsigned char> key(sizeof(K), 0);
     K* k = reinterpret_cast<K*>(key.data());

@@ -678,6 +678,8 @@ def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
         # kernels' wait policy pinned to the general default
         # the brick table through LDS as 16-bit pairs instead of 2-bit codes (and with the codes for a chromatic medium too)
         dict(VP_NO_LDS_COMPACT="1"), dict(VP_LDS_COMPACT_CHROMATIC="1"), dict(VP_NO_LDS_COMPACT="1", VP_NO_LDS_HELPER="1"),
+        # every volume treated as dense (no sun table, no approach walk for the decomposition estimator) / none
+        dict(VP_DENSE_PERCENT="0"), dict(VP_DENSE_PERCENT="101"),
         dict(VP_NO_OPACITY_LDS="1"), dict(VP_NO_OPACITY_CELLS="1"), dict(VP_NO_OPACITY_CELLS="1", VP_NO_OPACITY_LDS="1"), dict(VP_WAIT_LANES="24"),
     ]
     for env_set in settings:
@@ -771,7 +773,9 @@ def test_full_size_workloads_match_the_oracle_on_sampled_pixels(vp, oracle, work
     vp.render_frames(buf.ptr, first, frames, P)
     got = buf.download()
     buf.free()
-    assert vp.last_approach_mode() == 1          # the camera rays were walked ahead of the integrator (approach_k / approach_local_k)
+    # the camera rays were walked ahead of the integrator (approach_k / approach_local_k) -- except on the frame-filling cloud: more than
+    # 40 % of its cells have a non-empty neighbour, so the tables that pay in empty space (that walk, the sun table) are off (round 5)
+    assert vp.last_approach_mode() == (0 if workload == "c4f" else 1)
     cls = vp.pixel_table(P)[..., 5].astype(int)
     rng = np.random.default_rng(5)
     pick = []
