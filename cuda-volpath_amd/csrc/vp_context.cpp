@@ -115,7 +115,7 @@ int ensure_device()
     if (knob("VP_LOOKAHEAD_NO_SPECULATION", 0, 1, v)) G.la_speculate = v == 0;
     if (knob("VP_NO_LA_CANCEL", 0, 1, v)) G.la_cancel = v == 0;
     if (knob("VP_NO_EXIT", 0, 1, v)) G.use_exit = v == 0;
-    if (knob("VP_EXIT_LOCAL", 0, 1, v)) G.exit_local = v != 0;
+    if (knob("VP_EXIT_LOCAL", 0, 1, v)) { G.exit_local = v != 0; G.exit_local_auto = false; }
     if (knob("VP_EXIT_K", 1, VP_EXIT_TRIP, v)) G.exit_k = (unsigned)v;
     G.dev_ready = true;
     return VP_OK;
@@ -627,7 +627,7 @@ int vp_set_exit_flights(int mode)
     if (mode < 0 || mode > 2) return fail(VP_E_ARG, "exit flights: 0 off, 1 global-majorant estimator (default), 2 every estimator that has them");
     int rc = ensure_device();   // (first: it parses VP_NO_EXIT / VP_EXIT_LOCAL, which a later call must not override -- ADVICE r4)
     if (rc) return rc;
-    G.use_exit = mode != 0; G.exit_local = mode == 2;
+    G.use_exit = mode != 0; G.exit_local = mode == 2; G.exit_local_auto = false;
     if (G.use_exit && G.have_volume && !G.d_exit && G.d_danger)
     {
         // switched on after a volume was initialised without the table: build it now (the header promises the three modes unconditionally)

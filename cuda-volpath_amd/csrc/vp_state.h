@@ -179,7 +179,9 @@ struct State
     unsigned    h_bound_mask[8] = {};     // ... read back (ensure_bound_mask)
     // exit flights (render_k): per cell and class of directions, is every cell such a ray can meet empty?  Built with the volume
     bool        use_exit    = true;       // VP_NO_EXIT=1: every path walks to the box exit
-    bool        exit_local  = false;      // VP_EXIT_LOCAL=1: also for the local-majorant estimators (measured: nothing to gain there)
+    bool        exit_local  = false;      // VP_EXIT_LOCAL=1 / vp_set_exit_flights(2): also for the local-majorant estimators, whatever the stream
+    bool        exit_local_auto = true;   // until either is used: for the local-majorant estimators on the counter-based streams (round 5: C3 +3.9 %,
+                                          // c4s +1.6 %, c3ref +1 % with six-wave kernels; sampler.h +-0.5 %: profiles/experiments/r05_exit_local.txt)
     unsigned    exit_k      = 8;          // null collisions in empty space before a lane asks for the test (VP_EXIT_K)
     unsigned char* d_exit   = nullptr;
     float       light_key[7] = {};

@@ -219,11 +219,13 @@ int exit_flights(LaunchDev& L)
     if (!G.use_exit || !G.d_exit || !G.linear || G.trk || G.env_mis || G.est == VP_EST_BOUNDED) return VP_OK;
     if (G.est != VP_EST_GLOBAL)
     {
-        // Off by default: with local majorants the way out through empty bricks is a restart segment and ONE free flight per 0.05 of
-        // length, made by lanes that ride along with their wave's fetching lanes -- ending those paths early removes 11 % of the
-        // lane-steps of the decomposition workloads and not one wave-iteration (C3 +2 %, c3ref 0, c4s -0.5 %, sampler.h -1...-2 %:
-        // DESIGN.md section 5).  The global-majorant walk is 800 null collisions per unit length: there it is +27 %.
-        if (!G.exit_local || !G.quant) return VP_OK;
+        // With local majorants the way out through empty bricks is a restart segment and ONE free flight per 0.05 of length, made by
+        // lanes that ride along with their wave's fetching lanes: in round 4 ending those paths early removed 11 % of the lane-steps
+        // and not one wave-iteration (C3 +2 %, c3ref 0, c4s -0.5 %, sampler.h -1...-2 %) and stayed off.  Re-measured in round 5 with
+        // the six-wave kernels and the compact LDS table, 1024 frames per launch, noise floor 0.1 %: C3 +3.9 %, c4s +1.6 %, c3ref
+        // +1.0 ... 1.5 %, c4f 0; sampler.h +0.4 / -0.5 / +0.6 %.  On by default for the counter-based streams (exit_local_auto).
+        const bool local_on = G.exit_local_auto ? G.rng != VP_RNG_SAMPLERH : G.exit_local;
+        if (!local_on || !G.quant) return VP_OK;
         int rc = ensure_bound_mask();
         if (rc) return rc;
         unsigned nb = 0, packed = 0;

@@ -255,9 +255,10 @@ int vp_get_sun_clip_table(unsigned short* dst, size_t count, float* step);
  * other two axes in increasing order: every cell a ray from anywhere in `cell` with a direction of that class can meet is empty and
  * has empty neighbours.  Test hook for the certificate; VP_NO_EXIT=1 switches the table off. */
 int vp_get_exit_table(unsigned char* dst, size_t count);
-/* 0: off (every path walks to the box exit); 1 (default): the global-majorant estimator, where that walk is 800 null collisions per
+/* 0: off (every path walks to the box exit); 1: the global-majorant estimator only, where that walk is 800 null collisions per
  * unit length; 2: the decomposition estimator as well (uchar bound tables with at most four distinct maxima), where the walk is one
- * free flight per restart segment and ending it early is not measurably faster.  Performance only: the same bits in every mode. */
+ * free flight per restart segment.  Until this call is made (and without VP_EXIT_LOCAL): mode 2 on the counter-based streams
+ * (+1...4 % on the decomposition workloads), mode 1 on sampler.h.  Performance only: the same bits in every mode. */
 int vp_set_exit_flights(int mode);
 /* dst[n] = throughput of an unscattered path of the global-majorant estimator after n null collisions in empty space, n < count
  * (spectral tracking: the weight of such a collision is 1 only up to rounding; the light kernel looks the product up by n).

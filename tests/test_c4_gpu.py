@@ -670,7 +670,7 @@ def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
         dict(VP_NO_APPROACH="1"), dict(VP_NO_APPROACH_LOCAL="1"), dict(VP_APPROACH_STEPS="3"), dict(VP_APPROACH_STEPS="0"),
         dict(VP_APPROACH_STEPS="40", VP_NO_LDS_HELPER="1"), dict(VP_APPROACH_FRAMES_LOG2="0"), dict(VP_APPROACH_FRAMES_LOG2="1"),
         # exit flights (paths that can only leave the box are ended at once): off, tested at once, tested late
-        dict(VP_NO_EXIT="1"), dict(VP_EXIT_K="1"), dict(VP_EXIT_K="40"), dict(VP_EXIT_LOCAL="1"), dict(VP_EXIT_LOCAL="1", VP_EXIT_K="2"),
+        dict(VP_NO_EXIT="1"), dict(VP_EXIT_K="1"), dict(VP_EXIT_K="40"), dict(VP_EXIT_LOCAL="1"), dict(VP_EXIT_LOCAL="1", VP_EXIT_K="2"), dict(VP_EXIT_LOCAL="0"),
         # per-pixel constants staged for every frame instead of once per launch
         dict(VP_NO_CONST_ROWS="1"), dict(VP_NO_CONST_ROWS="1", VP_NO_LIGHT_CONST="1"),
         # round 5: the optical-depth table built by the gather kernel instead of through LDS tiles; read by the integrator from the plain
