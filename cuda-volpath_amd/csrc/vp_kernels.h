@@ -22,8 +22,10 @@
 #define VP_QUEUE_STRIDE 16  // words between queue heads (one cache line each)
 // the inner tracking loop of a wave runs until this many lanes are parked on an event, or until
 // a parked lane has waited this many steps
+// (28 since round 5 -- 24 before: C2 +1.3 % at the bench's launch size with a 0.15 % noise floor, the achromatic local kernels +0...0.3 %;
+// the chromatic local kernels take 32: vp_render.cpp, profiles/experiments/r05_knob_sweeps.txt)
 #ifndef VP_WAIT_LANES
-#define VP_WAIT_LANES 24
+#define VP_WAIT_LANES 28
 #endif
 #ifndef VP_WAIT_ITERS
 #define VP_WAIT_ITERS 16
