@@ -14,7 +14,8 @@
 #define VP_LDS_BYTES_PER_CU (160 * 1024)   // gfx950 (MI355X_MICROARCH.md); the static_assert at render_k's cold state ties the occupancy budgets to it
 #define VP_LDS_BOUND_ENTRIES 32768     // (max,min) byte pairs staged in LDS: 64 KiB
 #ifndef VP_CHUNK
-#define VP_CHUNK 256  // samples a wave takes from a queue per atomic
+#define VP_CHUNK 128  // samples a wave takes from a queue per atomic (256 until round 5: at the bench's launch size 128 is +1 % on the
+                      // Julia workloads -- finer hand-out at the end of a band --, 64 the same, 512 / 1024 -2 / -4 %: r05_knob_sweeps.txt)
 #endif
 // One sample queue per XCD: each hands out a contiguous band of the image (all frames of it), so the rays an XCD's
 // L2 serves stay in one slab of the volume; a wave starts on the queue of its own XCD and moves on when it runs dry.
