@@ -106,6 +106,26 @@ def test_two_rank_reduce_is_bit_identical():
     assert ok
 
 
+def test_eight_rank_reduce_is_bit_identical():
+    """BASELINE configs[4]'s rank count on the CPU: eight gloo ranks, each holding the oracle's frame restricted to ITS tiles of the
+    hashed row-shifted deal (vp_tile_owner's Python mirror), one reduce to rank 0: the sum of eight disjoint accumulators is the
+    one-rank image bit for bit.  (The GPU side of the same count: eight contexts of one process, tests/test_c4_gpu.py.)"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+    assert ok
+
+
 def _worker_frames(rank, world, port, q):
     import sys
     import numpy as np
