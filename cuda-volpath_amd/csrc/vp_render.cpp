@@ -82,6 +82,9 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
         // r05_knob_sweeps.txt).  Performance only: the knob test renders the same bits at 1...64.
         const bool ach = p->sigma_t.x == p->sigma_t.y && p->sigma_t.y == p->sigma_t.z && p->albedo.x == p->albedo.y && p->albedo.y == p->albedo.z;
         if (!G.wait_lanes_set && G.est != VP_EST_GLOBAL && !ach && G.trk == VP_TRACK_SPECTRAL) L.wait_lanes = 32;
+        // the sequential sampler.h stream (the parity mode): its shadow rays walk to their ends, a wave's lanes park later -- 24 lanes, the
+        // default of rounds 1-4, stays 0.8 % ahead of 28 on the reference's live configuration (profiles/r05_raw/sweep_samplerh.txt)
+        else if (!G.wait_lanes_set && G.rng == VP_RNG_SAMPLERH && G.trk == VP_TRACK_SPECTRAL) L.wait_lanes = 24;
     }
     if (sh.per_frame == 0) return VP_OK;
     rc = ensure_crawl_table(p, &L.crawl);
