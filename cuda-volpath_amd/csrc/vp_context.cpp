@@ -82,7 +82,12 @@ int ensure_device()
     if (knob("VP_LIGHT_WAIT_ITERS", VP_STEPS_PER_PASS, 1 << 20, v)) G.light_wait_iters = (unsigned)v;
     if (knob("VP_STAGE_MB", 1, 256 << 10, v)) G.max_stage_bytes = (size_t)v << 20;
     if (knob("VP_BLOCKS_PER_CU", 1, 8, v)) G.blocks_per_cu = (unsigned)v;
-    if (knob("VP_CHUNK_FRAMES_LOG2", 0, 8, v)) G.chunk_fshift = (unsigned)v;
+    {
+        // (a chunk is (VP_CHUNK >> k) pixels x 2^k frames: k beyond log2(VP_CHUNK) would leave it no pixel -- and the kernel a division by zero)
+        long kmax = 0;
+        while ((VP_CHUNK >> (kmax + 1)) >= 1) kmax++;
+        if (knob("VP_CHUNK_FRAMES_LOG2", 0, kmax, v)) G.chunk_fshift = (unsigned)v;
+    }
     if (knob("VP_NO_LDS_BOUNDS", 0, 1, v)) G.use_lds_bounds = v == 0;
     if (knob("VP_NO_LDS_HELPER", 0, 1, v)) G.lds_helper = v == 0;
     if (knob("VP_NO_LDS_COMPACT", 0, 1, v)) G.use_lds_compact = v == 0;

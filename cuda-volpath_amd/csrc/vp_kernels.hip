@@ -796,7 +796,8 @@ void render_k(SceneDev S, LaunchDev L)
                         // (the host sets chunk_fshift = 0 unless the frame count is a multiple): sample s of it is pixel s >> shift,
                         // frame s & mask -- with shift 6 a wave starts on ONE pixel in 64 frames: the same camera ray in every lane.
                         const unsigned q0 = L.q_start[q_cur], len = L.q_start[q_cur + 1] - q0;
-                        const unsigned sh = L.chunk_fshift, ppc = (unsigned)VP_CHUNK >> sh, fblocks = (unsigned)L.nframes >> sh;
+                        static_assert((VP_CHUNK & (VP_CHUNK - 1)) == 0 && VP_CHUNK >= 64, "VP_CHUNK: a power of two, at least a wave");
+                        const unsigned sh = L.chunk_fshift, ppc = (unsigned)VP_CHUNK >> sh, fblocks = (unsigned)L.nframes >> sh;   // (the host keeps sh <= log2(VP_CHUNK): ppc >= 1)
                         const unsigned cpf = (len + ppc - 1u) / ppc;
                         unsigned c = 0xffffffffu;
                         if (len)

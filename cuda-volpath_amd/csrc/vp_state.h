@@ -111,7 +111,7 @@ struct State
     unsigned    blocks_per_cu = 8;  // 256-thread workgroups per CU launched for a kernel that runs alone: as many as can be resident (seven of
                                     // the achromatic global-majorant kernel, six of the other plain ones, five of the chromatic local ones; a
                                     // workgroup too many starts when the queues are empty and ends at once)
-    unsigned    chunk_fshift = 0;         // VP_CHUNK_FRAMES_LOG2: a chunk = (256 >> k) pixels x (1 << k) frames (general class)
+    unsigned    chunk_fshift = 0;         // VP_CHUNK_FRAMES_LOG2: a chunk = (VP_CHUNK >> k) pixels x (1 << k) frames (general class), k <= log2(VP_CHUNK)
     bool        use_lds_bounds = true;
     bool        use_lds_compact = true;   // a brick table of at most four distinct pairs goes through LDS as 2-bit codes (VP_NO_LDS_COMPACT=1: as 16-bit pairs)
     bool        lds_compact_chromatic = false;   // ... for chromatic media too (VP_LDS_COMPACT_CHROMATIC=1: an A/B knob; measured slower)

@@ -284,12 +284,16 @@ def test_tuning_knobs_are_validated_and_never_change_results(tmp_path):
         "for est in (0, 1):\n"
         "    vp.init_volume(vp.julia_volume(32), brick=4 if est else 1); vp.init_envmap(scenes.synthetic_env())\n"
         "    vp.set_sun(scenes.DEFAULT_SUN_DIR, scenes.DEFAULT_SUN_POWER); vp.set_camera(); vp.set_estimator(est)\n"
-        "    vp.set_rng(vp.RNG_PHILOX, (3, 1)); b = vp.DeviceBuffer(W, H); vp.render_frames(b.ptr, 0, 6, vp.make_param(W, H, density=209.0, sigma_t=(0.3, 0.7, 1.0), albedo=(0.9, 0.8, 0.95)))\n"
+        "    if est: vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)\n"
+        "    vp.set_rng(vp.RNG_PHILOX, (3, 1)); b = vp.DeviceBuffer(W, H); vp.render_frames(b.ptr, 0, int(__import__('os').environ.get('VP_TEST_FRAMES', '6')), vp.make_param(W, H, density=209.0, sigma_t=(0.3, 0.7, 1.0), albedo=(0.9, 0.8, 0.95)))\n"
         "    out.append(hashlib.sha1(b.download().tobytes()).hexdigest())\n"
         "print('HASH', *out)\n"
     ) % (os.path.join(ROOT, "cuda-volpath_amd"), os.path.join(ROOT, "tests"))
     hashes = {}
-    for name, env in (("default", {}), ("bad", {"VP_WAIT_LANES": "0", "VP_BLOCKS_PER_CU": "0", "VP_STAGE_MB": "-5", "VP_WAIT_ITERS": "x"}),
+    # (VP_CHUNK_FRAMES_LOG2=8: a chunk of 128 samples cannot span 256 frames -- it would hold no pixel and the kernel would divide by
+    # zero; refused since the chunk went from 256 to 128 samples in round 5.  7, the largest shape that exists, is rendered: one pixel.)
+    for name, env in (("default", {}), ("bad", {"VP_WAIT_LANES": "0", "VP_BLOCKS_PER_CU": "0", "VP_STAGE_MB": "-5", "VP_WAIT_ITERS": "x", "VP_CHUNK_FRAMES_LOG2": "8"}),
+                      ("default128", {"VP_TEST_FRAMES": "128"}), ("one_pixel_chunks128", {"VP_TEST_FRAMES": "128", "VP_CHUNK_FRAMES_LOG2": "7"}),
                       ("no_tables", {"VP_NO_CRAWL_TABLE": "1", "VP_NO_EMPTY_TABLE": "1"}), ("no_light", {"VP_NO_LIGHT": "1"}),
                       ("no_overlap", {"VP_NO_LIGHT_OVERLAP": "1", "VP_SETUP_LANES": "1", "VP_WAIT_LANES": "32"}),
                       ("short_table", {"VP_THR_TABLE": "2", "VP_LIGHT_WAIT_ITERS": "16", "VP_LIGHT_BLOCKS_PER_CU": "1"})):
@@ -298,7 +302,8 @@ def test_tuning_knobs_are_validated_and_never_change_results(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         hashes[name] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
         if name == "bad":
-            assert r.stderr.count("ignoring VP_") == 4, r.stderr
+            assert r.stderr.count("ignoring VP_") == 5, r.stderr
+    assert hashes.pop("default128") == hashes.pop("one_pixel_chunks128")
     assert len(set(hashes.values())) == 1, hashes
 
 
