@@ -103,6 +103,7 @@ int ensure_device()
     if (knob("VP_NO_CONST_ROWS", 0, 1, v)) G.use_const_rows = v == 0;
     if (knob("VP_NO_APPROACH", 0, 1, v)) G.use_approach = v == 0;
     if (knob("VP_NO_APPROACH_LOCAL", 0, 1, v)) G.use_approach_local = v == 0;
+    if (knob("VP_NO_APPROACH_TABLE", 0, 1, v)) G.use_approach_table = v == 0;
     if (knob("VP_APPROACH_FRAMES_LOG2", 0, 6, v)) G.approach_fshift_max = (unsigned)v;
     if (knob("VP_APPROACH_STEPS", 0, 1 << 30, v)) G.approach_steps = (unsigned)v;
     if (knob("VP_NO_LIGHT", 0, 1, v)) G.use_light = v == 0;
@@ -558,6 +559,7 @@ int vp_ctx_destroy(vp_ctx* ctx)
         if (D.d_crawl) (void)hipFree(D.d_crawl);
         if (D.d_thr) (void)hipFree(D.d_thr);
         if (D.d_sunclip) (void)hipFree(D.d_sunclip);
+        if (D.d_seg) (void)hipFree(D.d_seg);
         if (D.d_bound_codes) (void)hipFree(D.d_bound_codes);
         if (D.d_light_flag) (void)hipFree(D.d_light_flag);
         if (D.d_tiles) (void)hipFree(D.d_tiles);

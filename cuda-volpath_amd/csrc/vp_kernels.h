@@ -143,6 +143,10 @@ struct LaunchDev
     const float4* stage_const;   // the staging row that holds the constants (the first frame of the batch the frames come from)
     const unsigned* bound_codes;   // the compact brick table (above): 2-bit codes ...
     unsigned        bound_pal[2];  // ... and the palette
+    // decomposition estimator, uchar bound table: per pixel slot of the general class the chain of restart segments of its camera
+    // ray through certified-empty cells (approach_segments_k: segment_table_records() float4 per slot); null: approach_local_k sets
+    // every segment up per sample
+    const float4* seg_table;
 };
 
 // lds_form: how the decomposition estimator reads its brick table -- 0 global memory, 1 the 16-bit table through LDS (512-thread
@@ -154,6 +158,10 @@ void launch_render_light(const SceneDev& S, const LaunchDev& L, int est, int rng
 void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimator, hipStream_t st);
 // the camera rays' free flights through certified-empty cells, one thread per sample of the launch (approach_k); rng: RNG_PHILOX*
 void launch_approach(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, hipStream_t st);
+// the per-pixel segment table of the decomposition estimator's approach walk (approach_segments_k): float4 per slot, and its builder
+unsigned segment_table_records(void);
+void launch_segment_table(const SceneDev& S, unsigned width, unsigned height, const float4* crawl, const unsigned* pixels, unsigned nslots, float4* seg,
+                          hipStream_t st);
 // throughput of an unscattered global-majorant path after n null collisions with density +0, n = 0..count-1 (thr_table_k)
 void launch_thr_table(const ParamDev& P, float* table, unsigned count, hipStream_t st);
 // mask[8]: the bytes that occur as a maximum in a uchar bound table; flag[0] (preset to 1) is cleared unless a null collision in

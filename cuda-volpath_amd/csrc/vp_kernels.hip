@@ -1949,6 +1949,140 @@ __global__ __launch_bounds__(256) void approach_local_k(SceneDev S, LaunchDev L)
     }
 }
 
+// ---- The approach walk of the decomposition estimator, with what depends on the PIXEL alone tabulated per pixel (round 5).
+// approach_local_k above sets every restart segment up per SAMPLE: box intersection, bound fetch, majorant, reciprocal, the neutrality
+// test -- ~75 of its ~130 vector instructions per segment -- although the camera ray, hence the chain of segment origins
+// ro_(n+1) = ro_n + rd * t_far_n and everything the set-up computes from them, is the same in every frame (quirk Q3); a wave of that
+// kernel is ONE pixel in 64 frames computing the same 75 instructions in 64 lanes.  approach_segments_k walks the chain once per pixel
+// of the general class (the identical binary32 operations, in the same order) and writes per segment (t_near, t_far, the brick's
+// bytes, a stop flag; the segment's origin, the certified-empty distance left at its start); approach_local_tab_k reads the records --
+// one 32-byte broadcast load per segment -- looks the majorant's reciprocal and its neutrality up by the byte (a 256-entry table in LDS,
+// computed per launch with the integrator's own expressions: they depend on Param), and makes what is left: the draws, the
+// logarithms, the sums and the compares.  Same hand-over, same bits (uchar bound tables; float tables keep approach_local_k).
+#define VP_SEG_CAP 96   // records per pixel: a box diagonal of 4.7 at 0.05 per segment; a longer chain is handed over where the table ends
+// layout per pixel slot, 2 * VP_SEG_CAP float4: [n] = (t_near, t_far, bound byte | stop << 8, t_empty at the segment's start),
+// [VP_SEG_CAP + n] = the segment's origin (read once per sample, at the hand-over)
+__global__ __launch_bounds__(256) void approach_segments_k(SceneDev S, unsigned width, unsigned height, const float4* crawl, const unsigned* pixels,
+                                                           unsigned nslots, float4* seg)
+{
+    const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nslots) return;
+    float4* out = seg + (size_t)slot * (2 * VP_SEG_CAP);
+    const unsigned pix = pixels[slot], px = pix & 0xffffu, py = pix >> 16;
+    if (px >= width || py >= height) { out[0] = make_float4(0.0f, 0.0f, u2f(0x100u), 0.0f); out[VP_SEG_CAP] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); return; }
+    f3 ro, rd;
+    camera_ray(S, width, height, px, py, ro, rd);
+    const f3     inv_rd = f3{1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
+    const size_t idx    = (size_t)px + (size_t)py * width;
+    const float4 c      = crawl[2 * idx];
+    float        t_empty = crawl[2 * idx + 1].x;
+    ro                  = f3{c.x, c.y, c.z};
+    for (unsigned n = 0; n < VP_SEG_CAP; n++)
+    {
+        // segment_setup() of render_k / approach_local_k (intersectSuperVolume kernel.cu:1626-1661): the same expressions
+        float t_near, tf;
+        const bool hit = intersect_box_inv(ro, inv_rd, S, t_near, tf);
+        t_near         = fmaxf(t_near, 0.0f);
+        const float t_far = fminf(tf, 0.05f);
+        const f3  pl = to_local(S, ro + rd * t_near);
+        const int bi = axis_point(pl.x, S.nx) >> S.brick_shift, bj = axis_point(pl.y, S.ny) >> S.brick_shift, bk = axis_point(pl.z, S.nz) >> S.brick_shift;
+        const unsigned v = reinterpret_cast<const unsigned short*>(S.bounds_u8)[(size_t)((unsigned)bi + (unsigned)S.bnx * ((unsigned)bj + (unsigned)S.bny * (unsigned)bk))];
+        // stop: the ray has left the box, the brick has a positive minimum (the control distance is the integrator's business), or the
+        // table ends here.  (NOT where the certificate is used up: a flight that leaves its segment needs no fetch, and in empty
+        // bricks nearly every flight does; the walk goes on as approach_local_k's does, flight by flight.)
+        const bool stop = !hit || (v >> 8) != 0u || n == VP_SEG_CAP - 1u;
+        out[n]              = make_float4(t_near, t_far, u2f((v & 0xffu) | (stop ? 0x100u : 0u)), t_empty);
+        out[VP_SEG_CAP + n] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+        if (stop) break;
+        ro      = ro + rd * t_far;   // tracking restart kernel.cu:2151-2155
+        t_empty -= t_far;
+    }
+}
+// A wave = one pixel in 64 frames (launched only with approach_fshift 6): it copies its pixel's chain into LDS with two coalesced loads
+// and walks it from there -- what a sample waits for per segment is an LDS read, not a dependent read of global memory (the first form,
+// records read from global memory segment by segment, took 17.0 of approach_local_k's 18.3 ms on C3 although it executes half the
+// instructions: profiles/experiments/r05_segment_table.txt).
+template <class RNG>
+__global__ __launch_bounds__(256) void approach_local_tab_k(SceneDev S, LaunchDev L)
+{
+    // per launch: for every byte a brick maximum can be, the reciprocal of the segment's majorant and whether a null collision in
+    // empty space leaves a throughput of 1 as it is under it -- approach_local_k's expressions, once per workgroup instead of per segment
+    __shared__ float4 chain[4][VP_SEG_CAP];
+    __shared__ float inv_tab[256];
+    __shared__ unsigned char ok_tab[256];
+    const unsigned wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const unsigned slot = blockIdx.x * 4u + wv, fl = (blockIdx.y << 6) + lane;
+    {
+        const ParamDev& P = L.P;
+        const float s           = hyperion_s(0 - 5);
+        const float reduction   = (1.0f - s) + s * (1.0f - P.g);
+        const float cur_density = reduction * P.density;
+        const float max_sig     = max3(f3{P.sigma_t[0], P.sigma_t[1], P.sigma_t[2]});
+        const unsigned b = threadIdx.x;   // 256 threads
+        const float d_max         = fmaxf(0.0001f, (float)b * VP_U8_SCALE);
+        const float sigma_t_prime = max_sig * cur_density * d_max;
+        const float inv_sigma     = 1.0f / sigma_t_prime;
+        inv_tab[b] = inv_sigma;
+        ok_tab[b]  = null_collision_in_empty_space(1.0f, sigma_t_prime, inv_sigma) == 1.0f ? 1 : 0;
+        if (slot < L.nslots)
+        {
+            // (records behind the chain's stop record were never written: read, never used)
+            const float4* rec = L.seg_table + (size_t)slot * (2 * VP_SEG_CAP);
+            chain[wv][lane] = rec[lane];
+            if (lane < VP_SEG_CAP - 64u) chain[wv][64u + lane] = rec[64u + lane];
+        }
+    }
+    __syncthreads();
+    if (approach_cancelled(L)) return;
+    if (slot >= L.nslots || fl >= (unsigned)L.nframes) return;
+    const ParamDev& P = L.P;
+    const unsigned pix = L.pixels[slot], px = pix & 0xffffu, py = pix >> 16;
+    if (px >= P.width || py >= P.height) return;
+    const size_t idx = (size_t)px + (size_t)py * P.width;
+    RNG rng;
+    rng.init(px, py, (unsigned)(L.frame0 + (int)fl), L.key0, L.key1);
+    rng.skip(f2u(L.crawl[2 * idx].w) >> 16);   // the crawl's draws
+    unsigned sa, sb;
+    rng.save(sa, sb);
+    float    d_reached = -1.0f;
+    unsigned n = 0;
+    unsigned long long n_steps = 0, n_segs = 0;
+    for (;; n++)
+    {
+        const float4 A = chain[wv][n];
+        const unsigned bits = f2u(A.z);
+        if ((bits & 0x100u) || n >= L.approach_steps || !ok_tab[bits & 0xffu]) break;   // handed over at this segment's origin
+        const float inv_sigma = inv_tab[bits & 0xffu], t_far = A.y, t_empty = A.w;
+        float    dist = A.x;
+        unsigned steps = 0;
+        bool     through = false;
+        unsigned ta = sa, tb = sb;   // the stream before the flight in hand
+        for (;;)
+        {
+            const float d2 = dist + -logf_(rng.next_a()) * inv_sigma;   // kernel.cu:2085
+            if (d2 >= t_far) { through = true; break; }
+            if (!(d2 < t_empty) || steps > 60000u) break;                 // a fetch: render_k's
+            dist = d2;
+            (void)rng.next_b();
+            rng.save(ta, tb);
+            steps++;
+        }
+        n_steps += steps;
+        if (!through) { d_reached = dist; sa = ta; sb = tb; break; }
+        rng.save(sa, sb);
+        n_segs++;
+    }
+    const float4 O = L.seg_table[(size_t)slot * (2 * VP_SEG_CAP) + VP_SEG_CAP + n];
+    const size_t item = (size_t)fl * L.stage_stride + L.slot_base + slot;
+    L.stage[item] = make_float4(O.x, O.y, O.z, d_reached);
+    L.approach_aux[item] = make_uint2(sa, sb);
+    if (L.counters)
+    {
+        if (n_steps) atomicAdd(&L.counters[1], n_steps);
+        if (n_segs) atomicAdd(&L.counters[2], n_segs);
+    }
+}
+
 // expand a dense volume into per-voxel 2x2x2 neighbourhood cells (clamped at the border)
 __device__ __forceinline__ size_t pack_index(int nx, int ny, int i, int j, int k, int bricks)
 {
@@ -2493,6 +2627,12 @@ void launch_miss_fill(const SceneDev& S, const LaunchDev& L, bool local_estimato
 {
     hipLaunchKernelGGL(miss_fill_k, dim3((L.nslots + 255) / 256), dim3(256), 0, st, S, L, local_estimator ? 1 : 0);
 }
+unsigned segment_table_records(void) { return 2u * VP_SEG_CAP; }
+void launch_segment_table(const SceneDev& S, unsigned width, unsigned height, const float4* crawl, const unsigned* pixels, unsigned nslots, float4* seg,
+                          hipStream_t st)
+{
+    hipLaunchKernelGGL(approach_segments_k, dim3((nslots + 255u) / 256u), dim3(256), 0, st, S, width, height, crawl, pixels, nslots, seg);
+}
 void launch_approach(const SceneDev& S, const LaunchDev& L, int est, int rng, bool quant, hipStream_t st)
 {
     const unsigned sh = L.approach_fshift, spb = 256u >> sh;   // pixel slots per workgroup
@@ -2502,6 +2642,14 @@ void launch_approach(const SceneDev& S, const LaunchDev& L, int est, int rng, bo
         if (rng == RNG_PHILOX7) hipLaunchKernelGGL(approach_k<RngPhilox7>, grid, dim3(256), 0, st, S, L);
         else if (rng == RNG_PHILOX) hipLaunchKernelGGL(approach_k<RngPhilox>, grid, dim3(256), 0, st, S, L);
         else hipLaunchKernelGGL(approach_k<RngSamplerH>, grid, dim3(256), 0, st, S, L);
+    }
+    else if (quant && L.seg_table && sh == 6u)
+    {
+        static_assert(VP_SEG_CAP > 64 && VP_SEG_CAP <= 128, "approach_local_tab_k copies a chain with two loads per lane");
+        // (uchar bound table, the per-pixel segment table built: the set-up of every restart segment comes from it)
+        if (rng == RNG_PHILOX7) hipLaunchKernelGGL(approach_local_tab_k<RngPhilox7>, grid, dim3(256), 0, st, S, L);
+        else if (rng == RNG_PHILOX) hipLaunchKernelGGL(approach_local_tab_k<RngPhilox>, grid, dim3(256), 0, st, S, L);
+        else hipLaunchKernelGGL(approach_local_tab_k<RngSamplerH>, grid, dim3(256), 0, st, S, L);
     }
     else if (quant)
     {

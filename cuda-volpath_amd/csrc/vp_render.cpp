@@ -132,6 +132,13 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
             approach_thr = true;
         }
     }
+    // (decomposition estimator: the restart segments of every general pixel's camera ray, tabulated once per view)
+    L.seg_table = nullptr;
+    if (approach && G.est == VP_EST_DECOMP && nframes >= 64 && G.approach_fshift_max >= 6)   // (read by waves of one pixel x 64 frames)
+    {
+        rc = ensure_segment_table(p, L.crawl, &L.seg_table);
+        if (rc) return rc;
+    }
     const size_t per_frame = sh.per_frame;
     if (0xfffffff0u / per_frame < 1) return fail(VP_E_ARG, "image too large for the 32-bit sample queue");
     L.stage_stride = (unsigned)per_frame;
@@ -322,6 +329,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                 ClassTimer ct(0, T.stream);
                 L.approach = 0;
                 G.last_approach = 0;
+                G.last_approach_table = 0;
                 const bool aux_ok = !appr_aux_needed || G.d_appr_aux[T.index] != nullptr;
                 if (appr_aux_needed) L.approach_aux = G.d_appr_aux[T.index];
                 if (approach && aux_ok && L.stage && f <= 65535)
@@ -333,6 +341,7 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                     launch_approach(S, L, G.est, G.rng, G.quant, T.stream);
                     le = hipGetLastError();
                     G.last_approach = (int)L.approach;
+                    G.last_approach_table = (G.est == VP_EST_DECOMP && G.quant && L.seg_table && L.approach_fshift == 6u) ? 1 : 0;
                     // the helper workgroups of the LDS-table kernel (auxiliary stream, below) read the staging slots as well: their
                     // fork point moves behind the walk
                     if (lds_helper && fork_recorded && le == hipSuccess)
@@ -467,6 +476,7 @@ int vp_render_time_ms(double* total_ms, int* launches, int reset)
     return VP_OK;
 }
 int vp_last_approach_mode(void) { return G.last_approach; }
+int vp_last_approach_table(void) { return G.last_approach_table; }
 int vp_last_light_const(void) { return G.last_light_const; }
 int vp_last_lds_form(void) { return G.last_lds_form; }
 int vp_lookahead_stats(unsigned* launched, unsigned* cancelled_in_flight)

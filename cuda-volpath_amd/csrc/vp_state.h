@@ -165,11 +165,16 @@ struct State
     uint2*      d_appr_aux[3] = {nullptr, nullptr, nullptr};   // per render target (caller's stream, two look-ahead slots): LaunchDev::approach_aux
     size_t      appr_aux_bytes[3] = {0, 0, 0};
     int         last_approach = 0;            // vp_last_approach_mode
+    int         last_approach_table = 0;      // vp_last_approach_table
     int         last_light_const = 0;         // vp_last_light_const
     int         last_lds_form = 0;            // vp_last_lds_form
     unsigned    la_launched = 0, la_cancelled = 0;   // vp_lookahead_stats
     bool        use_const_rows = true;        // VP_NO_CONST_ROWS=1: per-pixel constants are staged for every frame, as before round 4's end
     unsigned    last_const_from = 0;          // LaunchDev::const_from of the last staged launch (a look-ahead slot keeps it for its add-kernels)
+    bool        use_approach_table = true;    // ... with the restart segments of a pixel's camera ray tabulated per pixel (VP_NO_APPROACH_TABLE=1: set up per sample)
+    float4*     d_seg = nullptr;              // the table (approach_segments_k), its size and what it was built for
+    size_t      seg_bytes = 0;
+    std::vector<unsigned char> seg_key;
     bool        use_approach_local = true;    // ... and approach_local_k ahead of the decomposition estimator (VP_NO_APPROACH_LOCAL=1: off)
     bool        use_approach = true;          // approach_k ahead of the global-majorant integrator (VP_NO_APPROACH=1: off)
     unsigned    approach_fshift_max = 6;      // a wave of the approach kernels = one pixel x 2^6 frames (VP_APPROACH_FRAMES_LOG2: 0 = 64 pixels of one frame)
@@ -256,6 +261,7 @@ int    ensure_bound_mask();
 int    exit_flights(LaunchDev& L);
 int    ensure_thr_table(const Param* p, const float** out);
 int    ensure_pixel_lists(const Param* p, const float4* table, const Shard& sh);
+int    ensure_segment_table(const Param* p, const float4* crawl, const float4** out);
 // ---- vp_render.cpp
 // where a launch stages its samples: the caller's stream and buffers, or a look-ahead slot's
 struct Target { hipStream_t stream; float4** stage; size_t* stage_bytes; unsigned* queue; int index; };

@@ -303,6 +303,42 @@ int ensure_thr_table(const Param* p, const float** out)
 // table -- the light class (camera rays that meet certified-empty cells over their whole chord) and the pixels whose camera ray
 // misses the box.  Built on the GPU (pixlist_*_k: a stable three-way partition of the tile-ordered pixels by the class in the pixel
 // table; the host only reads back the three counts).  Rebuilt when the image size, the shard or the table changes.
+// The chain of restart segments of every general pixel's camera ray (vp_kernels.hip approach_segments_k): what approach_local_tab_k
+// reads instead of setting every segment up per sample.  Depends on what the crawl table depends on (camera, box, volume, bound
+// table, image size) and on the pixel list; rebuilt with either.  Best effort: without it approach_local_k walks as before.
+int ensure_segment_table(const Param* p, const float4* crawl, const float4** out)
+{
+    *out = nullptr;
+    if (!G.use_approach_table || !crawl || !G.quant || G.est != VP_EST_DECOMP || !G.n_general || !G.d_tiles) return VP_OK;
+    std::vector<unsigned char> key = G.crawl_key;
+    key.insert(key.end(), G.tiles_key.begin(), G.tiles_key.end());
+    const size_t need = (size_t)G.n_general * segment_table_records() * sizeof(float4);
+    if (key != G.seg_key || !G.d_seg)
+    {
+        if (la_quiesce()) return VP_E_NODEVICE;   // batches in flight read the old table
+        HIPCHK(hipStreamSynchronize(G.stream));
+        if (need > G.seg_bytes)
+        {
+            if (G.d_seg) HIPCHK(hipFree(G.d_seg));
+            G.d_seg = nullptr; G.seg_bytes = 0; G.seg_key.clear();
+            if (hipMalloc((void**)&G.d_seg, need) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                G.d_seg = nullptr;
+                return VP_OK;   // no table: every sample sets its segments up itself, same bits
+            }
+            G.seg_bytes = need;
+        }
+        SceneDev S = G.S;
+        S.linear   = G.linear ? 1 : 0;
+        launch_segment_table(S, p->width, p->height, crawl, G.d_tiles, G.n_general, G.d_seg, G.stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(G.stream));   // (launches on other streams read it)
+        G.seg_key = key;
+    }
+    *out = G.d_seg;
+    return VP_OK;
+}
 int ensure_pixel_lists(const Param* p, const float4* table, const Shard& sh)
 {
     const bool light = G.use_light && table && G.trk == VP_TRACK_SPECTRAL && !(G.est != VP_EST_GLOBAL && !G.use_light_local);

@@ -24,7 +24,7 @@ PART1_SYMBOLS = ["init_cuda", "set_texture_filter_mode", "free_cuda_buffers", "p
                  "render_kernel", "scale", "gamma_correct"]
 PART2_SYMBOLS = ["vp_last_error", "vp_version", "vp_device_count", "vp_set_device", "vp_set_stream", "vp_get_stream", "vp_synchronize",
                  "vp_set_estimator", "vp_set_rng", "vp_set_envmap_sampling", "vp_get_env_tables", "vp_set_lookahead", "vp_set_tracking", "vp_set_bound_brick", "vp_set_shard", "vp_render_frames",
-                 "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity", "vp_get_pixel_table", "vp_get_null_collision_table", "vp_get_sun_clip_table", "vp_get_exit_table", "vp_set_exit_flights", "vp_render_class_time_ms", "vp_last_approach_mode", "vp_last_light_const", "vp_last_lds_form", "vp_lookahead_stats", "vp_prepare", "vp_reserve_frames", "vp_get_pixel_lists",
+                 "vp_enable_counters", "vp_read_counters", "vp_render_time_ms", "vp_get_bound_table", "vp_get_opacity", "vp_get_pixel_table", "vp_get_null_collision_table", "vp_get_sun_clip_table", "vp_get_exit_table", "vp_set_exit_flights", "vp_render_class_time_ms", "vp_last_approach_mode", "vp_last_approach_table", "vp_last_light_const", "vp_last_lds_form", "vp_lookahead_stats", "vp_prepare", "vp_reserve_frames", "vp_get_pixel_lists",
                  "vp_julia_voxelize", "vp_cloud_voxelize", "vp_test_math", "vp_test_rng", "vp_test_sample_density", "vp_test_hg", "vp_test_intersect_box",
                  "vp_test_eval_envmap", "vp_ctx_create", "vp_ctx_destroy", "vp_ctx_set_current", "vp_ctx_get_current", "vp_ctx_device",
                  "vp_accumulate", "vp_tile_owner", "vp_malloc", "vp_free", "vp_memset",
@@ -326,6 +326,11 @@ def render_class_time_ms(reset=True):
 def last_approach_mode():
     """0 / 1 / 2: how the last render launch took its general pixels' camera rays to the medium (vp_last_approach_mode)"""
     return int(lib().vp_last_approach_mode())
+
+
+def last_approach_table():
+    """1 if that walk read the per-view table of restart segments (vp_last_approach_table)"""
+    return int(lib().vp_last_approach_table())
 
 
 def reserve_frames(P, nframes):

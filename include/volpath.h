@@ -211,6 +211,9 @@ int vp_render_class_time_ms(double ms[3], unsigned pixels[3], int reset);
  * certified-empty stretch ahead of it, 2 = as 1 with the walked throughput looked up by the number of steps (a global-majorant
  * medium whose null collision in empty space is not neutral).  Never changes a result. */
 int vp_last_approach_mode(void);
+/* 1 if that walk (decomposition estimator, launches of 64 frames and more) read the restart segments of each pixel's camera ray from
+ * the per-view table (approach_segments_k) instead of setting them up per sample; VP_NO_APPROACH_TABLE=1 switches the table off. */
+int vp_last_approach_table(void);
 /* 1 if the last render call of this context wrote its light class (pixels whose camera ray meets empty cells only) as per-pixel
  * constants (miss_fill_k: a null collision in empty space leaves a throughput of 1 as it is in this medium), 0 if it integrated it. */
 int vp_last_light_const(void);

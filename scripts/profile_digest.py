@@ -1,7 +1,7 @@
 """Digest of scripts/profile_bench.sh output: per-launch averages of the render launch.
 
-A render launch is the general kernel render_k<..., LIGHT=false> -- behind approach_k where the global-majorant estimator runs on a
-counter-based stream -- and, where the workload has light pixels that are not per-pixel constants, the light kernel
+A render launch is the general kernel render_k<..., LIGHT=false> -- behind approach_k / approach_local_k / approach_local_tab_k, the
+camera rays' walk ahead of it -- and, where the workload has light pixels that are not per-pixel constants, the light kernel
 render_k<..., LIGHT=true> beside it on a second stream; bench.py times the pair with HIP events from the start of the first
 to the end of the last.  Counters are summed over these kernels of the timed (non-counting) variant and divided by the number
 of launches (= dispatches of the general kernel)."""
@@ -12,7 +12,7 @@ res = {}
 
 def variant(name):
     name = re.sub(r"RngPhiloxR<\d+>", "RngPhiloxR", name)
-    if "approach_k<" in name or "approach_local_k<" in name:
+    if "approach_k<" in name or "approach_local_k<" in name or "approach_local_tab_k<" in name:
         # the camera rays' free flights ahead of the global-majorant general kernel: part of the launch, summed like the light kernel
         return {"count": False, "light": False, "approach": True}
     m = re.search(r"render_k<([^>]*)>", name)
@@ -22,9 +22,11 @@ def variant(name):
     return {"count": a[3] == "true", "light": len(a) > 8 and a[8] == "true", "approach": False}
 
 
-ks = glob.glob(f"{out}/kt/**/*kernel_stats.csv", recursive=True)
+import os
+# (gpurun merges a call's files into what earlier calls left: the newest pass counts)
+ks = sorted(glob.glob(f"{out}/kt/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime, reverse=True)
 if ks:
-    rows = [(r, variant(r["Name"])) for r in csv.DictReader(open(ks[0])) if "render_k" in r["Name"] or "approach_k" in r["Name"] or "approach_local_k" in r["Name"]]
+    rows = [(r, variant(r["Name"])) for r in csv.DictReader(open(ks[0])) if "render_k" in r["Name"] or "approach_k" in r["Name"] or "approach_local_k" in r["Name"] or "approach_local_tab_k" in r["Name"]]
     rows = [(r, v) for r, v in rows if v and not v["count"]]
     for key, light, appr in (("kernel_trace", False, False), ("kernel_trace_light", True, False), ("kernel_trace_approach", False, True)):
         sel = [r for r, v in rows if v["light"] == light and v["approach"] == appr]
@@ -33,7 +35,7 @@ if ks:
             res[key] = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                         "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"])}
 for d in ("fetch", "write", "sq", "sq2", "tcc"):
-    for f in glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True):
+    for f in sorted(glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:
         agg = collections.defaultdict(float); disp = collections.defaultdict(set)
         for r in csv.DictReader(open(f)):
             v = variant(r["Kernel_Name"])

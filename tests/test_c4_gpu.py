@@ -672,7 +672,7 @@ def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
         dict(VP_WAIT_LANES="5", VP_WAIT_ITERS="4", VP_SETUP_LANES="1", VP_END_LANES="1"), dict(VP_END_LANES="40", VP_SETUP_LANES="33"),
         dict(VP_STAGE_MB="1", VP_BLOCKS_PER_CU="2"), dict(VP_NO_LIGHT_OVERLAP="1", VP_NO_LIGHT_CONST="1"),
         # the camera rays' walk ahead of the integrator (approach_k / approach_local_k): off, cut short after a few steps / segments
-        dict(VP_NO_APPROACH="1"), dict(VP_NO_APPROACH_LOCAL="1"), dict(VP_APPROACH_STEPS="3"), dict(VP_APPROACH_STEPS="0"),
+        dict(VP_NO_APPROACH="1"), dict(VP_NO_APPROACH_LOCAL="1"), dict(VP_NO_APPROACH_TABLE="1"), dict(VP_NO_APPROACH_TABLE="1", VP_APPROACH_STEPS="3"), dict(VP_APPROACH_STEPS="3"), dict(VP_APPROACH_STEPS="0"),
         dict(VP_APPROACH_STEPS="40", VP_NO_LDS_HELPER="1"), dict(VP_APPROACH_FRAMES_LOG2="0"), dict(VP_APPROACH_FRAMES_LOG2="1"),
         # exit flights (paths that can only leave the box are ended at once): off, tested at once, tested late
         dict(VP_NO_EXIT="1"), dict(VP_EXIT_K="1"), dict(VP_EXIT_K="40"), dict(VP_EXIT_LOCAL="1"), dict(VP_EXIT_LOCAL="1", VP_EXIT_K="2"), dict(VP_EXIT_LOCAL="0"),

@@ -113,6 +113,59 @@ def test_approach_kernels_walk_the_estimators_steps(vp, oracle, est, brick, dens
     buf.free()
 
 
+@pytest.mark.parametrize("brick,density", [(1, 800.0), (8, 800.0), (8, 209.0)])
+@pytest.mark.parametrize("rng_mode", [0, 2])
+def test_approach_walk_reads_the_segment_table_from_64_frames_on(vp, oracle, brick, density, rng_mode, monkeypatch):
+    """Round 5: in launches of 64 frames and more the decomposition estimator's walk (a wave = one pixel in 64 frames) reads the
+    restart segments of its pixel's camera ray from a per-view table (approach_segments_k -> approach_local_tab_k) instead of
+    setting each one up per sample.  70 frames (a full block of 64 and a ragged one), across the frame-11 switch: image == oracle,
+    the work counters with the walk tallied == oracle, the same with the walk cut short (VP_APPROACH_STEPS: the table's records
+    beyond the cut are not walked) and with the table switched off (a context of its own: knobs are read at creation)."""
+    grid = oracle.julia(64)
+    osc, oP, vP = _setup(vp, oracle, grid, 1, rng_mode, brick=brick, key=(5, 77), P_kw=dict(density=density))
+    osc.precompute_opacity()
+    vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+    frames = list(range(3, 73))
+    ref, cnt = _oracle_frames(osc, oP, frames)
+    buf = vp.DeviceBuffer(W, H)
+    vp.render_frames(buf.ptr, frames[0], len(frames), vP)
+    assert np.array_equal(buf.download(), ref)
+    assert vp.last_approach_mode() == 1 and vp.last_approach_table() == 1
+    vp.render_frames(buf.ptr, frames[0], 6, vP)          # a short launch walks without the table
+    assert vp.last_approach_mode() == 1 and vp.last_approach_table() == 0
+    monkeypatch.setenv("VP_COUNT_APPROACH", "1")
+    buf.reset()
+    vp.enable_counters(True)
+    vp.read_counters(reset=True)
+    vp.render_frames(buf.ptr, frames[0], len(frames), vP)
+    got = buf.download()
+    c = vp.read_counters()
+    vp.enable_counters(False)
+    assert np.array_equal(got, ref)
+    assert vp.last_approach_table() == 1
+    for k in ("samples", "density_lookups", "bound_lookups", "opacity_lookups", "env_lookups", "scatters"):
+        assert c[k] == cnt[k], (k, c[k], cnt[k])
+    buf.free()
+    monkeypatch.delenv("VP_COUNT_APPROACH")
+    for env_set, table in ((dict(VP_APPROACH_STEPS="3"), 1), (dict(VP_NO_APPROACH_TABLE="1"), 0), (dict(VP_APPROACH_FRAMES_LOG2="5"), 0)):
+        for k, v in env_set.items():
+            monkeypatch.setenv(k, v)
+        ctx = vp.Context(0)
+        for k in env_set:
+            monkeypatch.delenv(k)
+        try:
+            with ctx:
+                _setup(vp, oracle, grid, 1, rng_mode, brick=brick, key=(5, 77), P_kw=dict(density=density))
+                vp.precompute_opacity(scenes.DEFAULT_SUN_DIR)
+                b2 = vp.DeviceBuffer(W, H)
+                vp.render_frames(b2.ptr, frames[0], len(frames), vP)
+                assert np.array_equal(b2.download(), ref), env_set
+                assert vp.last_approach_table() == table, env_set
+                b2.free()
+        finally:
+            ctx.destroy()
+
+
 @pytest.mark.parametrize("brick", [1, 8])
 def test_julia64_chromatic_bricks(vp, oracle, brick):
     grid = oracle.julia(64)
