@@ -174,6 +174,75 @@ def test_random_scene_bit_exact(vp, oracle, seed):
         buf.free()
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VP_FUZZ_LONG", "12"))))
+def test_random_scene_long_launch_bit_exact(vp, oracle, seed, monkeypatch):
+    """Launches of 64 frames and more take paths of their own: the approach walk's waves are one pixel in 64 frames, and the
+    decomposition estimator's walk then reads the per-view segment table (round 5, approach_segments_k -> approach_local_tab_k).
+    Random scenes as above -- cropped to 20^3 voxels so that the oracle's optical-depth precompute stays cheap -- with the
+    decomposition or the global-majorant estimator, spectral tracking, 64...100 frames across the frame-11 switch, a few pixels.
+    Odd seeds render in a context that never takes a volume for dense (VP_DENSE_PERCENT=101: these small random grids mostly
+    are, and a dense volume gets no walk), so that the walk -- and its table, on uchar volumes -- runs in most of them."""
+    from volpath import host
+    c = _case(5000 + seed, host)
+    rng = np.random.default_rng(77 + seed)
+    c["grid"] = np.ascontiguousarray(c["grid"][:20, :20, :20])
+    if c["grid"].dtype != np.uint8 and rng.random() < 0.7:
+        c["grid"] = np.ascontiguousarray((np.clip(c["grid"], 0.0, 1.0) * 255.0).astype(np.uint8))
+    c["est"] = int(rng.choice([1, 1, 1, 0]))
+    c["brick"] = int(rng.choice([1, 2, 4, 8])) if c["est"] else 1
+    c["env_mis"], c["track"] = False, 0
+    c["W"], c["H"] = int(rng.integers(3, 20)), int(rng.integers(3, 14))
+    c["first"], c["nframes"] = int(rng.choice([0, 5, 11, 40])), int(rng.integers(64, 101))
+    c["late"] = c["est"] == 1
+    ref, cnt = _oracle_render(oracle, c)
+    vP = vp.make_param(c["W"], c["H"], **c["kw"])
+    what = dict(seed=seed, grid=c["grid"].shape, dtype=str(c["grid"].dtype), box=c["box"], est=c["est"], rng=c["rng_mode"], linear=c["linear"],
+                brick=c["brick"], size=(c["W"], c["H"]), first=c["first"], nframes=c["nframes"], **c["kw"])
+    ctx = None
+    if seed & 1:
+        monkeypatch.setenv("VP_DENSE_PERCENT", "101")
+        ctx = vp.Context(0)
+        monkeypatch.delenv("VP_DENSE_PERCENT")
+        ctx.__enter__()
+    buf = vp.DeviceBuffer(c["W"], c["H"])
+    try:
+        vp.init_volume(c["grid"], box=c["box"], brick=c["brick"], linear=c["linear"])
+        vp.init_envmap(c["env"])
+        vp.set_sun(c["sun_dir"], c["sun_power"])
+        vp.set_camera(c["cam"])
+        vp.set_estimator(c["est"])
+        vp.set_rng(c["rng_mode"], c["key"])
+        vp.set_tracking(0)
+        vp.set_envmap_sampling(vp.ENV_PASSIVE)
+        vp.set_shard(0, 1)
+        if c["late"]:
+            vp.precompute_opacity(c["sun_dir"])
+        vp.render_frames(buf.ptr, c["first"], c["nframes"], vP)
+        got = buf.download()
+        assert np.array_equal(got, ref, equal_nan=True), (what, float(np.nanmax(np.abs(got - ref))))
+        # the table is read exactly where it can be: the decomposition estimator's walk over a uchar volume
+        want_table = c["est"] == 1 and vp.last_approach_mode() == 1 and c["grid"].dtype == np.uint8
+        assert vp.last_approach_table() == (1 if want_table else 0), what
+        if __import__("os").environ.get("VP_FUZZ_VERBOSE"):
+            print(f"seed {seed}: est {c['est']} {c['grid'].dtype} approach mode {vp.last_approach_mode()} table {vp.last_approach_table()}")
+        vp.enable_counters(True)
+        vp.read_counters(reset=True)
+        buf.reset()
+        vp.render_frames(buf.ptr, c["first"], c["nframes"], vP)
+        k = vp.read_counters()
+        vp.enable_counters(False)
+        assert np.array_equal(buf.download(), ref, equal_nan=True), what
+        for q in ("samples", "density_lookups", "bound_lookups", "opacity_lookups", "env_lookups", "scatters"):
+            assert k[q] == cnt[q], (what, q, k[q], cnt[q])
+    finally:
+        vp.enable_counters(False)
+        vp.set_camera()
+        buf.free()
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+            ctx.destroy()
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VP_FUZZ_BINARY", "16"))))
 def test_random_binary_volume_takes_the_compact_lds_table(vp, oracle, seed):
     """Round 5: a brick table with at most four distinct (max,min) pairs goes through LDS as 2-bit codes beside the cold per-path state
