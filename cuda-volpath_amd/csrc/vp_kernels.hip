@@ -292,6 +292,19 @@ void render_k(SceneDev S, LaunchDev L)
         for (int w = threadIdx.x; w < n16; w += VP_BLOCK_LDS) dst[w] = src[w];
         __syncthreads();
     }
+    // The kernel arguments once more, in LDS (round 5).  The event section and light_done() read their uniforms -- camera, sun,
+    // environment, queue and image descriptors: ~70 scalars the tracking loop never touches -- afresh at every visit instead of holding
+    // them in SGPRs across the loop (round 3).  They did so with flat loads of the argument segment: L1/L2 round trips of their own, and
+    // every s_waitcnt vmcnt(0) behind one also waits for the wave's density fetches.  An LDS read waits for itself only.
+    // VP_EXP_FLAT_KARGS: the flat loads, for the A/B (profiles/experiments/r05_kargs_lds.txt).
+    constexpr unsigned KARG_L_   = ((sizeof(SceneDev) + alignof(LaunchDev) - 1) / alignof(LaunchDev)) * alignof(LaunchDev);
+    constexpr unsigned KARG_WDS_ = (KARG_L_ + sizeof(LaunchDev) + 3) / 4;
+    __shared__ __attribute__((aligned(16))) unsigned kargs_lds_[KARG_WDS_];
+    {
+        const unsigned* src = (const unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+        for (unsigned w = threadIdx.x; w < KARG_WDS_; w += (LDSB == 1 ? VP_BLOCK_LDS : VP_BLOCK)) kargs_lds_[w] = src[w];
+        __syncthreads();
+    }
     constexpr bool LOCAL = EST != EST_GLOBAL;  // the two local-majorant estimators share the segment logic
     // Counter-based streams, passive environment: ONE event visit per collision.  The shadow ray draws from a sub-stream of its own,
     // so the two phase-function variates -- the path's next draws -- are the same whether they are taken before or after it: the
@@ -328,7 +341,7 @@ void render_k(SceneDev S, LaunchDev L)
     constexpr int  CS_  = COLD ? VP_BLOCK : 1;
     // (the occupancy these kernels are budgeted for holds only while that many workgroups' cold state fits the CU's LDS --
     // a workgroup is one wave per SIMD, so waves per SIMD = workgroups per CU; gfx950: 160 KiB)
-    static_assert(!COLD || (VP_GLOBAL_MIN_WAVES > VP_LOCAL_MIN_WAVES ? VP_GLOBAL_MIN_WAVES : VP_LOCAL_MIN_WAVES) * (14 * VP_BLOCK * 4 + (LDSB == 2 ? VP_LDS_BOUND_ENTRIES / 4 : 0)) <= VP_LDS_BYTES_PER_CU,
+    static_assert(!COLD || (VP_GLOBAL_MIN_WAVES > VP_LOCAL_MIN_WAVES ? VP_GLOBAL_MIN_WAVES : VP_LOCAL_MIN_WAVES) * (14 * VP_BLOCK * 4 + KARG_WDS_ * 4 + (LDSB == 2 ? VP_LDS_BOUND_ENTRIES / 4 : 0)) <= VP_LDS_BYTES_PER_CU,
                   "cold per-path state: more workgroups per CU than the LDS holds -- lower VP_*_MIN_WAVES for this ARCH");
     __shared__ float cold_[COLD ? 14 : 1][CS_];
     float* const cold_p = &cold_[0][COLD ? threadIdx.x : 0];
@@ -413,14 +426,20 @@ void render_k(SceneDev S, LaunchDev L)
         // tracking loop never touches) from the kernel-argument segment afresh in every visit instead of holding them in SGPRs
         // across the tracking loop, whose own scalars then fit without spilling into vector lanes.  The empty asm keeps the
         // compiler from hoisting those loads back out of the loop; it also makes the pointer divergent for it, so the reads are
-        // per-lane flat loads of the fields a visit's branches need (one L1-resident line for every wave of the CU), not scalar
-        // loads -- which, tried, load the whole structs and spill 35-49 SGPRs: -20...-45 % (profiles/experiments/
-        // r03_scalar_kernarg_reload.txt).
+        // per-lane loads of the fields a visit's branches need, not scalar loads -- which, tried, load the whole structs and spill
+        // 35-49 SGPRs: -20...-45 % (profiles/experiments/r03_scalar_kernarg_reload.txt).  Rounds 3-4: flat loads of the argument
+        // segment; round 5: reads of its copy in LDS (kargs_lds_, above).
         {
+#ifdef VP_EXP_FLAT_KARGS
         const char* kargs_ = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kargs_));
+#else
+        unsigned ko_ = 0;
+        asm volatile("" : "+v"(ko_));   // (an opaque offset: the reads stay LDS reads and stay inside the visit)
+        const char* kargs_ = reinterpret_cast<const char*>(kargs_lds_) + ko_;
+#endif
         const SceneDev&  S = *reinterpret_cast<const SceneDev*>(kargs_);
-        const LaunchDev& L = *reinterpret_cast<const LaunchDev*>(kargs_ + ((sizeof(SceneDev) + alignof(LaunchDev) - 1) / alignof(LaunchDev)) * alignof(LaunchDev));
+        const LaunchDev& L = *reinterpret_cast<const LaunchDev*>(kargs_ + KARG_L_);
         const ParamDev&  P = L.P;
         const f3 sun_dir   = f3{S.sun_dir[0], S.sun_dir[1], S.sun_dir[2]};
         const f3 sun_power = f3{S.sun_power[0], S.sun_power[1], S.sun_power[2]};
@@ -1043,13 +1062,19 @@ ends_done:
         };
         // EARLY: a shadow ray has ended (nee_a known): add the light and go on with the segment prepared in the collision block
         auto light_done = [&]() __attribute__((always_inline)) {
+#ifdef VP_EXP_FLAT_KARGS
             const char* ka_ = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka_));   // the sun's power is read here, not held in scalar registers across the loop
+#else
+            unsigned ko2_ = 0;
+            asm volatile("" : "+v"(ko2_));
+            const char* ka_ = reinterpret_cast<const char*>(kargs_lds_) + ko2_;
+#endif
             const SceneDev& S2 = *reinterpret_cast<const SceneDev*>(ka_);
             const f3 sunp = f3{S2.sun_power[0], S2.sun_power[1], S2.sun_power[2]};
             rad = rad + sunp * (((ACH ? f3{thr.x, thr.x, thr.x} : thr) * ph) * nee_a);
             rd  = pd;
-            if (EXITC) terms = reinterpret_cast<const LaunchDev*>(ka_ + ((sizeof(SceneDev) + alignof(LaunchDev) - 1) / alignof(LaunchDev)) * alignof(LaunchDev))->exit_start;
+            if (EXITC) terms = reinterpret_cast<const LaunchDev*>(ka_ + KARG_L_)->exit_start;
             if (EST == EST_GLOBAL)
             {
                 nsc = nsc + 1;

@@ -76,15 +76,12 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
     L.key0 = G.key0; L.key1 = G.key1;
     L.wait_lanes = G.wait_lanes; L.wait_iters = G.wait_iters; L.setup_lanes = G.setup_lanes; L.end_lanes = G.end_lanes;
     {
-        // The chromatic local-majorant kernels (BASELINE configs[3]/[4]'s shape) wait for 32 parked lanes instead of 24: their event pass
-        // is the most expensive (three-channel collision block, the optical-depth lookup) and comes every four steps on a frame-filling
-        // cloud; round 5's sweep with a 0.05 % noise floor: c4f +1.6 %, every other workload within its noise (profiles/experiments/
-        // r05_knob_sweeps.txt).  Performance only: the knob test renders the same bits at 1...64.
-        const bool ach = p->sigma_t.x == p->sigma_t.y && p->sigma_t.y == p->sigma_t.z && p->albedo.x == p->albedo.y && p->albedo.y == p->albedo.z;
-        if (!G.wait_lanes_set && G.est != VP_EST_GLOBAL && !ach && G.trk == VP_TRACK_SPECTRAL) L.wait_lanes = 32;
+        // (Rounds 4-5 gave the chromatic local-majorant kernels 32 parked lanes: their event pass was the most expensive.  Since the event
+        // section reads its uniforms from LDS -- vp_kernels.hip kargs_lds_ -- a visit is cheap enough that the general default is the
+        // better one there too: c4s +1.1 %, c4f +0.9 % at 28, profiles/experiments/r05_kargs_lds.txt.  Performance only.)
         // the sequential sampler.h stream (the parity mode): its shadow rays walk to their ends, a wave's lanes park later -- 24 lanes, the
         // default of rounds 1-4, stays 0.8 % ahead of 28 on the reference's live configuration (profiles/r05_raw/sweep_samplerh.txt)
-        else if (!G.wait_lanes_set && G.rng == VP_RNG_SAMPLERH && G.trk == VP_TRACK_SPECTRAL) L.wait_lanes = 24;
+        if (!G.wait_lanes_set && G.rng == VP_RNG_SAMPLERH && G.trk == VP_TRACK_SPECTRAL) L.wait_lanes = 24;
     }
     if (sh.per_frame == 0) return VP_OK;
     rc = ensure_crawl_table(p, &L.crawl);
