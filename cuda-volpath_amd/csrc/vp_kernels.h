@@ -47,7 +47,8 @@
 #define VP_PROFILE_BLOCKS 0   // 1: the counting kernels also carry cycle stamps, loop statistics and block tallies (scripts/block_profile.py)
 #endif
 #ifndef VP_GLOBAL_MIN_WAVES
-#define VP_GLOBAL_MIN_WAVES 6  // achromatic global-majorant kernel: waves per SIMD its register budget is held to.  Six since the cold
+#define VP_GLOBAL_MIN_WAVES 6  // achromatic global-majorant kernel: waves per SIMD its register budget is held to (79 registers since the event section reads its
+                               // uniforms from LDS: six waves; 72 = seven before, and held to 72 now it spills six: 2743 vs 2999 on C2).  Six since the cold
                                // per-path state lives in LDS (round 4: 79 registers, no spill); with that state in registers six cost
                                // three spilled registers and lost to five (1190 vs 1341 Msamples/s on C2, round 3)
 #endif
