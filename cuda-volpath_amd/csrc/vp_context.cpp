@@ -92,6 +92,7 @@ int ensure_device()
     if (knob("VP_NO_LDS_HELPER", 0, 1, v)) G.lds_helper = v == 0;
     if (knob("VP_NO_LDS_COMPACT", 0, 1, v)) G.use_lds_compact = v == 0;
     if (knob("VP_LDS_COMPACT_CHROMATIC", 0, 1, v)) G.lds_compact_chromatic = v != 0;
+    if (knob("VP_LDS_PAIRS", 0, 1, v)) G.lds_pairs = v != 0;
     if (knob("VP_CELL_BRICKS", 0, 1, v)) G.cell_bricks = (int)v;
     if (knob("VP_NO_CRAWL_TABLE", 0, 1, v)) G.use_crawl_table = v == 0;
     if (knob("VP_NO_EMPTY_TABLE", 0, 1, v)) G.use_empty_table = v == 0;

@@ -47,10 +47,11 @@
 #define VP_PROFILE_BLOCKS 0   // 1: the counting kernels also carry cycle stamps, loop statistics and block tallies (scripts/block_profile.py)
 #endif
 #ifndef VP_GLOBAL_MIN_WAVES
-#define VP_GLOBAL_MIN_WAVES 6  // achromatic global-majorant kernel: waves per SIMD its register budget is held to (79 registers since the event section reads its
-                               // uniforms from LDS: six waves; 72 = seven before, and held to 72 now it spills six: 2743 vs 2999 on C2).  Six since the cold
-                               // per-path state lives in LDS (round 4: 79 registers, no spill); with that state in registers six cost
-                               // three spilled registers and lost to five (1190 vs 1341 Msamples/s on C2, round 3)
+#define VP_GLOBAL_MIN_WAVES 7  // global-majorant kernels: waves per SIMD their register budget is held to.  Seven = 72 registers, no spill, since
+                               // intersect_box runs axis by axis (vp_device.h; round 5): C2 3010-3030 -> 3090.  History: six since the cold
+                               // per-path state lives in LDS (round 4: 79 registers; it came out at 72 = seven by itself until the event section
+                               // read its uniforms from LDS: 79 again, and held to 72 THEN it spilled six: 2743 vs 2999); with the cold state in
+                               // registers six cost three spilled registers and lost to five (1190 vs 1341 Msamples/s on C2, round 3)
 #endif
 #ifndef VP_LIGHT_LOCAL_MIN_WAVES
 #define VP_LIGHT_LOCAL_MIN_WAVES 7   // the local-majorant light kernels need 66-68 registers with the Philox2x32-10 and sampler.h streams:

@@ -213,12 +213,17 @@ int do_render(vp_float4* d_out, int first, int nframes, const Param* p, bool sta
                                 (size_t)S.bnx * S.bny * S.bnz <= (size_t)VP_LDS_BOUND_ENTRIES;
         // ... as 2-bit codes where it has at most four distinct pairs (round 5): the plain kernel's registers and occupancy with the table
         // in LDS.  Timed launches of the counter-based streams; counting launches and look-ahead batches keep the 16-bit form.
-        // ACHROMATIC media only: measured (profiles/experiments/r05_lds_compact_table.txt) -- C3 +2.4 % over the 16-bit table and its
-        // helper workgroup, level with the table read from global memory; the chromatic kernel (90 registers, five waves either way)
-        // is 1.7 % FASTER with four 16-bit-table waves and the helper's fifth (c4s), so it keeps them.
+        // Chromatic media too, since their kernel fits six waves per SIMD (79 registers: intersect_box axis by axis, vp_device.h): c4s
+        // 1935 with the 16-bit table and its helper, 2001 from global memory, 2024 with the codes (profiles/experiments/r05_box_sequence.txt;
+        // before that change 1.7 % behind the 16-bit table: r05_lds_compact_table.txt).  VP_LDS_COMPACT_CHROMATIC=0: not.
+        // A table that cannot go as codes: for those launches from GLOBAL memory (six / five waves) rather than as 16-bit pairs through LDS
+        // (four waves and a helper workgroup) -- c4f +1.6 %; C3 was level already (round 5).  VP_LDS_PAIRS=1: the pairs.
         const bool ach_lds = p->sigma_t.x == p->sigma_t.y && p->sigma_t.y == p->sigma_t.z && p->albedo.x == p->albedo.y && p->albedo.y == p->albedo.z;
-        const int lds_form = !lds_bounds ? 0 : (G.bound_codes_ok && G.d_bound_codes && !G.count && !tgt && G.rng != VP_RNG_SAMPLERH &&
-                                                (ach_lds || G.lds_compact_chromatic)) ? 2 : 1;
+        // (the sequential sampler.h stream has no codes kernel; its timed launches, too, are ahead without the pairs: c3 +2.2 %, c4s +4.3 %)
+        const bool timed_l  = !G.count && !tgt;                       // a timed launch (not a counting one, not a look-ahead batch)
+        const bool timed_cb = timed_l && G.rng != VP_RNG_SAMPLERH;    // ... of a counter-based stream
+        const int lds_form = !lds_bounds ? 0 : (G.bound_codes_ok && G.d_bound_codes && timed_cb && (ach_lds || G.lds_compact_chromatic)) ? 2
+                                             : (timed_l && !G.lds_pairs) ? 0 : 1;
         G.last_lds_form = lds_form;
         L.bound_codes = lds_form == 2 ? G.d_bound_codes : nullptr;
         L.bound_pal[0] = G.bound_pal[0]; L.bound_pal[1] = G.bound_pal[1];

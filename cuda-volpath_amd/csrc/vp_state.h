@@ -114,7 +114,10 @@ struct State
     unsigned    chunk_fshift = 0;         // VP_CHUNK_FRAMES_LOG2: a chunk = (VP_CHUNK >> k) pixels x (1 << k) frames (general class), k <= log2(VP_CHUNK)
     bool        use_lds_bounds = true;
     bool        use_lds_compact = true;   // a brick table of at most four distinct pairs goes through LDS as 2-bit codes (VP_NO_LDS_COMPACT=1: as 16-bit pairs)
-    bool        lds_compact_chromatic = false;   // ... for chromatic media too (VP_LDS_COMPACT_CHROMATIC=1: an A/B knob; measured slower)
+    bool        lds_compact_chromatic = true;    // ... for chromatic media too (VP_LDS_COMPACT_CHROMATIC=0: not; since their kernel fits six waves
+                                                 // -- 79 registers, intersect_box axis by axis -- the codes beat the 16-bit table and its helper: c4s +4.4 %)
+    bool        lds_pairs = false;               // timed launches of the counter-based streams whose table cannot go as codes read it from global memory
+                                                 // (six waves) rather than as 16-bit pairs through LDS (four and a helper): c4f +1.6 %.  VP_LDS_PAIRS=1: the pairs
     unsigned*   d_bound_codes = nullptr;  // ... the codes (built with the volume), and the palette
     unsigned    bound_pal[2] = {0, 0};
     bool        bound_codes_ok = false;

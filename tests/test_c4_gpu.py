@@ -681,8 +681,10 @@ def test_results_do_not_depend_on_the_tuning_knobs(vp, oracle, est, brick):
         # round 5: the optical-depth table built by the gather kernel instead of through LDS tiles; read by the integrator from the plain
         # table instead of the packed cells (what happens by itself where the 8x copy cannot be allocated: ADVICE r4); the chromatic
         # kernels' wait policy pinned to the general default
-        # the brick table through LDS as 16-bit pairs instead of 2-bit codes (and with the codes for a chromatic medium too)
-        dict(VP_NO_LDS_COMPACT="1"), dict(VP_LDS_COMPACT_CHROMATIC="1"), dict(VP_NO_LDS_COMPACT="1", VP_NO_LDS_HELPER="1"),
+        # the brick table through LDS as 16-bit pairs instead of 2-bit codes (and without the codes for a chromatic medium)
+        dict(VP_NO_LDS_COMPACT="1"), dict(VP_LDS_COMPACT_CHROMATIC="0"), dict(VP_NO_LDS_COMPACT="1", VP_NO_LDS_HELPER="1"),
+        # ... as 16-bit pairs where it cannot go as codes (the default reads it from global memory then), with and without the helper
+        dict(VP_LDS_PAIRS="1"), dict(VP_LDS_PAIRS="1", VP_NO_LDS_COMPACT="1"), dict(VP_LDS_PAIRS="1", VP_NO_LDS_COMPACT="1", VP_NO_LDS_HELPER="1"),
         # every volume treated as dense (no sun table, no approach walk for the decomposition estimator) / none
         dict(VP_DENSE_PERCENT="0"), dict(VP_DENSE_PERCENT="101"),
         dict(VP_NO_OPACITY_LDS="1"), dict(VP_NO_OPACITY_CELLS="1"), dict(VP_NO_OPACITY_CELLS="1", VP_NO_OPACITY_LDS="1"), dict(VP_WAIT_LANES="24"),

@@ -246,8 +246,8 @@ def test_random_scene_long_launch_bit_exact(vp, oracle, seed, monkeypatch):
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VP_FUZZ_BINARY", "16"))))
 def test_random_binary_volume_takes_the_compact_lds_table(vp, oracle, seed):
     """Round 5: a brick table with at most four distinct (max,min) pairs goes through LDS as 2-bit codes beside the cold per-path state
-    (render_k<..., LDSB = 2>) -- for achromatic media, timed launches, counter-based streams; chromatic media, counting launches, the
-    sampler.h stream and frame-by-frame render_kernel calls keep the 16-bit table or global memory.  The randomised scenes above are
+    (render_k<..., LDSB = 2>) -- timed launches of the counter-based streams; the sampler.h stream's read it from global memory, counting
+    launches and frame-by-frame render_kernel calls keep the 16-bit table or global memory.  The randomised scenes above are
     soft volumes (hundreds of pairs) and never take that form: these are BINARY volumes {0, v} of random ragged shapes, random boxes,
     cameras, media, brick sizes and first frames (half of them across the frame-11 switch), decomposition estimator.  The timed
     launch, the counting launch and the frame-by-frame path must all equal the oracle bit for bit; vp_last_lds_form says which form
@@ -309,7 +309,8 @@ def test_random_binary_volume_takes_the_compact_lds_table(vp, oracle, seed):
         got = buf.download()
         form = vp.last_lds_form()
         assert np.array_equal(got, ref, equal_nan=True), (what, form, float(np.nanmax(np.abs(got - ref))))
-        assert form == (2 if (not chromatic and rng_mode != 0) else 1), (what, form)
+        # (chromatic media too, since their kernel fits six waves; the sampler.h stream has no codes kernel and reads the table from global memory: round 5)
+        assert form == (2 if rng_mode != 0 else 0), (what, form)
         vp.enable_counters(True)                                     # the counting launch: the 16-bit table, the estimator's counters
         vp.read_counters(reset=True)
         buf.reset()
